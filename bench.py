@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the segmentation-network hot path on MI355X.
+
+A step is one forward pass (the replacement of `model(batch, training=False)`,
+/root/reference utils/predict.py:159) of ResNet-34 U-Net, 3 classes, over one
+batch of synthetic 1920x2560x3 images per GPU with the inputs already resident
+in HBM; images are independent, so ranks share nothing and no collective is on
+the data path (weak scaling).  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak of MI355X
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_images(n, h, w, seed=1234):
+    """uint8 uniform noise -> per-image min-max to [0,1] (utils/data.py:64-80)."""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8).astype(np.float32)
+    lo = img.reshape(n, -1).min(axis=1)[:, None, None, None]
+    hi = img.reshape(n, -1).max(axis=1)[:, None, None, None]
+    return (img - lo) / (hi - lo)
+
+
+def build_weights(graph, seed=1234):
+    from miseg_amd import weights as W
+    return W.init_weights(graph, seed=seed, randomize_bn=True)
+
+
+def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
+    """Time the CPU oracle (torch-CPU back-end, fp32) on one image of the same
+    workload, on this host's cores.  Test infrastructure used as a reported
+    baseline only."""
+    from oracle import nets, ops_torch
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    torch.set_num_threads(threads)
+    x = synthetic_images(1, h, w, seed=99)
+    small = synthetic_images(1, 256, 256, seed=98)
+    with torch.no_grad():
+        nets.forward(ops_torch, encoder, decoder, weights, small)      # warm-up
+        t0 = time.perf_counter()
+        n_done = 0
+        while True:
+            nets.forward(ops_torch, encoder, decoder, weights, x)
+            n_done += 1
+            el = time.perf_counter() - t0
+            if el > budget_s * 0.5 or n_done >= 3:
+                break
+    return {"value": n_done / el, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d forward pass(es) of 1 image %dx%dx3, oracle/nets.py on torch-CPU fp32 "
+                      "(TensorFlow reference not installable offline)" % (n_done, h, w)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU per step")
+    ap.add_argument("--height", type=int, default=1920)
+    ap.add_argument("--width", type=int, default=2560)
+    ap.add_argument("--encoder", default="resnet34")
+    ap.add_argument("--decoder", default="U-Net")
+    ap.add_argument("--classes", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-op", action="store_true", help="print a per-kernel table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import miseg_amd
+    from miseg_amd import engine, netspec
+
+    h, w = args.height, args.width
+    graph = netspec.build_graph(args.encoder, args.decoder, (h, w, 3), args.classes)
+    weights = build_weights(graph)
+    eng = engine.Engine(graph, weights, batch=args.batch, device=str(dev))
+    x = torch.from_numpy(synthetic_images(args.batch, h, w, seed=1234 + rank)).to(dev)
+    eng.x_in.copy_(x)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        eng.run()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        # per-kernel timing with HIP events on the launch stream
+        nops = eng.num_ops
+        reps = 5
+        op_ms = np.zeros(nops)
+        for _ in range(reps):
+            for i in range(nops):
+                op_ms[i] += eng.time_ops(i, i + 1)
+        op_ms /= reps
+        macs = np.array([eng.op_macs(i) for i in range(nops)], dtype=np.float64)
+        is_conv = macs > 0
+        conv_ms = op_ms[is_conv].sum()
+        conv_flops = 2.0 * macs.sum()
+        dom = int(np.argmax(op_ms))
+        dom_tflops = 2.0 * macs[dom] / (op_ms[dom] * 1e-3) / 1e12
+        if args.per_op:
+            for i in range(nops):
+                tf = 2.0 * macs[i] / (op_ms[i] * 1e-3) / 1e12 if macs[i] else 0.0
+                print("%3d %-32s %8.3f ms %8.2f GMAC %8.1f TFLOP/s" %
+                      (i, eng.op_names[i], op_ms[i], macs[i] / 1e9, tf), file=sys.stderr)
+            print("sum of per-op times %.3f ms (conv %.3f ms)" % (op_ms.sum(), conv_ms), file=sys.stderr)
+        images = args.batch * world * args.steps
+        result = {
+            "metric": "images/sec at 1920x2560x3 ResNet-34 U-Net inference",
+            "value": images / elapsed,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {"workload": "%s %s inference %dx%dx3, %d classes, random-init weights, "
+                                   "batch %d per GPU per step" %
+                                   (args.encoder, args.decoder, h, w, args.classes, args.batch),
+                       "images_per_step_per_gpu": args.batch,
+                       "parallelism": "independent images per GPU, no collective"},
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "conv_igemm_kernel launch '%s'" % eng.op_names[dom],
+                "achieved": dom_tflops,
+                "peak": MFMA_BF16_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS,
+                "traffic": None,
+                "launch_ms": op_ms[dom],
+                "all_conv_launches": {
+                    "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
+                    "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                    "gflop_per_step": conv_flops / 1e9, "ms_per_step": conv_ms,
+                    "non_conv_ms_per_step": float(op_ms[~is_conv].sum())},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.encoder, args.decoder, args.classes, h, w, weights)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

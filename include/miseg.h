@@ -1,0 +1,211 @@
+/*
+ * miseg.h -- C ABI of libmiseg.so: the MI355X (gfx950) device kernels behind the
+ * segmentation-network forward pass that the reference builds at
+ * utils/model.py:145-236 and runs at utils/predict.py:159.
+ *
+ * The reference has no FFI of its own: every arithmetic step of this path is a
+ * tf.keras layer call.  Each entry point below therefore cites the Keras layer
+ * family (and the reference line that instantiates it) it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative MISEG_E_* code otherwise;
+ *     miseg_last_error() returns a thread-local message for the last failure;
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing here
+ *     allocates or frees device memory;
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - activations are NHWC; "strides" are in ELEMENTS of the tensor's dtype and
+ *     let a tensor be a channel slice of a wider buffer (concatenation without
+ *     copies) or a strided/offset view (transpose-conv phases);
+ *   - bf16 = upper 16 bits of an IEEE float32, round-to-nearest-even.
+ */
+#ifndef MISEG_H
+#define MISEG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISEG_OK 0
+#define MISEG_E_INVALID_ARG (-1)
+#define MISEG_E_UNSUPPORTED_SHAPE (-2)
+#define MISEG_E_HIP (-3)
+#define MISEG_E_NO_DEVICE (-4)
+
+#define MISEG_DT_BF16 0
+#define MISEG_DT_F32 1
+
+/* epilogue of the main output */
+#define MISEG_ACT_NONE 0
+#define MISEG_ACT_RELU 1
+#define MISEG_ACT_SOFTMAX 2 /* over Cout (<= 4), fp32 output, optional u8 collapse */
+#define MISEG_ACT_SIGMOID 3
+
+const char* miseg_last_error(void);
+int miseg_version(void);
+/* 0 if the current HIP device is a gfx950; MISEG_E_NO_DEVICE otherwise. */
+int miseg_device_check(void);
+
+/*
+ * Convolution as implicit GEMM on bf16 MFMA with fp32 accumulation.
+ * Replaces keras Conv2D / ZeroPadding2D+Conv2D / Conv2DTranspose(4,2,'same')
+ * and the BatchNormalization+Activation('relu')+Add that surround them in
+ * classification_models ResNet, keras_applications DenseNet and the
+ * segmentation_models decoders (reached from utils/model.py:176,188,200).
+ *
+ *   acc[n,oy,ox,co] = sum_{dy,dx,ci} A[n, oy*stride_y - pad_y + dy,
+ *                                        ox*stride_x - pad_x + dx, ci] * Wt[co,dy,dx,ci]
+ *   A = in, or relu(in*in_scale[ci] + in_shift[ci]) when in_scale != NULL
+ *       (taps outside the image contribute zero in both cases);
+ *   v    = acc*scale[co] + shift[co] (+ residual[n,oy,ox,co]);
+ *   out  = act(v)                           (dtype out_dtype; skipped if out == NULL)
+ *   out2 = relu(v*scale2[co] + shift2[co])  (bf16; skipped if out2 == NULL)
+ *
+ * transposed != 0 selects Conv2DTranspose(kernel 4, stride 2, 'same'): the call
+ * computes the four output phases (a,b) in {0,1}^2 as 2x2 convolutions,
+ * out[n, 2y+a, 2x+b, co]; `weight` then holds [4][Cout][2][2][Cin] and
+ * KH = KW = 2, strides 1, Ho = H, Wo = W; the out, out2 and res strides describe the
+ * full-resolution (2H x 2W) tensor.
+ *
+ * weight layout: bf16 [Cout][KH][KW][Cin], Cin contiguous.  Cin % 32 == 0.
+ */
+typedef struct miseg_conv_desc {
+  const void* in;
+  const void* weight;
+  void* out;
+  void* out2;
+  const void* residual;
+  const float* scale;
+  const float* shift;
+  const float* scale2;
+  const float* shift2;
+  const float* in_scale;
+  const float* in_shift;
+  void* collapse_out; /* MISEG_ACT_SOFTMAX only: u8 [N,Ho,Wo,Cout] strict-argmax mask, or NULL */
+  int32_t N, H, W, Cin;
+  int32_t Ho, Wo, Cout;
+  int32_t KH, KW, stride_y, stride_x, pad_y, pad_x;
+  int32_t in_pix_stride, in_row_stride;
+  int64_t in_img_stride;
+  int32_t out_pix_stride, out_row_stride;
+  int64_t out_img_stride;
+  int32_t out2_pix_stride, out2_row_stride;
+  int64_t out2_img_stride;
+  int32_t res_pix_stride, res_row_stride;
+  int64_t res_img_stride;
+  int32_t out_dtype; /* MISEG_DT_* */
+  int32_t res_dtype; /* MISEG_DT_* */
+  int32_t act;       /* MISEG_ACT_* */
+  int32_t transposed;
+  float temperature;       /* MISEG_ACT_SOFTMAX: logits are divided by it */
+  int32_t collapse_value;  /* value written for the winning channel (127) */
+  int32_t tile_hint;       /* 0 = choose automatically */
+} miseg_conv_desc;
+
+int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);
+
+/*
+ * Input contract of the encoders: fp32 NHWC image with 3 channels ->
+ * bf16 [N][H+6][W+8][4] with the image at rows 3.., columns 3.., channel 3 and
+ * the border zero; value = x*scale[c] + shift[c] (ResNet `bn_data`, a
+ * BatchNormalization(scale=False) on the raw input followed by
+ * ZeroPadding2D(3); identity scale for DenseNet).  Feeds the 7x7 stride-2 stem.
+ */
+int miseg_prep_input(const float* in, void* out, const float* scale, const float* shift,
+                     int32_t N, int32_t H, int32_t W, void* stream);
+
+/*
+ * ZeroPadding2D(1) + MaxPooling2D(3, strides 2) on a non-negative bf16 tensor,
+ * optionally followed by y = relu(y*scale[c] + shift[c]) (the first ResNet
+ * unit's bn1+relu1).  C % 8 == 0.
+ */
+int miseg_maxpool3x3s2_fwd(const void* in, void* out, const float* scale, const float* shift,
+                           int32_t N, int32_t H, int32_t W, int32_t C,
+                           int32_t in_pix_stride, int32_t out_pix_stride, void* stream);
+
+/* AveragePooling2D(2, strides 2) on bf16 (DenseNet transition `poolK_pool`). */
+int miseg_avgpool2x2_fwd(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t in_pix_stride, int32_t out_pix_stride, void* stream);
+
+/*
+ * out[n,y,x,c] = in[n, y>>shift, x>>shift, c] (+ addend[n,y,x,c] if addend != NULL)
+ * UpSampling2D nearest x2/x4/x8 (+ Add) of the FPN top-down path and the
+ * `upsampling_stage{3,4,5}` layers writing into the aggregation buffer.
+ * H, W are the INPUT dims.  bf16, C % 8 == 0.
+ */
+int miseg_upsample_nearest_fwd(const void* in, const void* addend, void* out,
+                               int32_t N, int32_t H, int32_t W, int32_t C, int32_t shift,
+                               int32_t in_pix_stride, int32_t add_pix_stride,
+                               int32_t out_pix_stride, void* stream);
+
+/* UpSampling2D(2, 'bilinear') with half-pixel centres (FPN `final_upsampling`). */
+int miseg_upsample_bilinear2x_fwd(const void* in, void* out, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, int32_t in_pix_stride, int32_t out_pix_stride,
+                                  void* stream);
+
+/* y = relu(x*scale[c] + shift[c]) on bf16 (a stand-alone BatchNormalization+ReLU). */
+int miseg_scale_shift_relu_fwd(const void* in, void* out, const float* scale, const float* shift,
+                               int64_t pixels, int32_t C, int32_t in_pix_stride,
+                               int32_t out_pix_stride, void* stream);
+
+/*
+ * collapse_probabilities (utils/utils.py:50-68) on device: fp32 probabilities
+ * [pixels][C] -> u8 [pixels][C]; channels are decided in order and channel i is
+ * compared with the already-collapsed values of the channels before it, as the
+ * reference's in-place loop does.
+ */
+int miseg_collapse_u8(const float* probs, uint8_t* out, int64_t pixels, int32_t C,
+                      int32_t value, void* stream);
+
+/*
+ * Sums for cce_dice_loss / f1-score / iou_score (segmentation_models
+ * base.functional, selected at model_train.py:172-179) over fp32 [pixels][C]
+ * tensors, C <= 8.  sums (double[4*C], zeroed by the call) receives, per class,
+ * sum(gt*pr), sum(pr), sum(gt), sum(gt*log(clip(pr/sum_c pr))).
+ */
+int miseg_loss_sums(const float* gt, const float* pr, double* sums, int64_t pixels, int32_t C,
+                    void* stream);
+
+/*
+ * A plan is a recorded list of the calls above with fixed arguments, replayed
+ * with one call per forward pass (the analogue of the compiled tf.function
+ * behind model(batch, training=False), utils/predict.py:159).
+ */
+typedef struct miseg_plan miseg_plan;
+miseg_plan* miseg_plan_create(void);
+void miseg_plan_destroy(miseg_plan* p);
+int miseg_plan_num_ops(const miseg_plan* p);
+int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d);
+int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
+                              const float* shift, int32_t N, int32_t H, int32_t W);
+int miseg_plan_add_maxpool3x3s2(miseg_plan* p, const void* in, void* out, const float* scale,
+                                const float* shift, int32_t N, int32_t H, int32_t W, int32_t C,
+                                int32_t in_pix_stride, int32_t out_pix_stride);
+int miseg_plan_add_avgpool2x2(miseg_plan* p, const void* in, void* out, int32_t N, int32_t H,
+                              int32_t W, int32_t C, int32_t in_pix_stride,
+                              int32_t out_pix_stride);
+int miseg_plan_add_upsample_nearest(miseg_plan* p, const void* in, const void* addend, void* out,
+                                    int32_t N, int32_t H, int32_t W, int32_t C, int32_t shift,
+                                    int32_t in_pix_stride, int32_t add_pix_stride,
+                                    int32_t out_pix_stride);
+int miseg_plan_add_upsample_bilinear2x(miseg_plan* p, const void* in, void* out, int32_t N,
+                                       int32_t H, int32_t W, int32_t C, int32_t in_pix_stride,
+                                       int32_t out_pix_stride);
+int miseg_plan_add_scale_shift_relu(miseg_plan* p, const void* in, void* out, const float* scale,
+                                    const float* shift, int64_t pixels, int32_t C,
+                                    int32_t in_pix_stride, int32_t out_pix_stride);
+/* Launch every recorded op, in order, on `stream`. */
+int miseg_plan_run(const miseg_plan* p, void* stream);
+/*
+ * Launch ops [first, last) and, when ms != NULL, time them with HIP events
+ * recorded on `stream` (synchronises the stream): *ms = elapsed milliseconds.
+ */
+int miseg_plan_run_range(const miseg_plan* p, int first, int last, void* stream, float* ms);
+/* Algorithmic multiply-accumulates of conv op `index` (0 for other ops). */
+int64_t miseg_plan_op_macs(const miseg_plan* p, int index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISEG_H */

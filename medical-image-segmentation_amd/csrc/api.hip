@@ -1,0 +1,264 @@
+// C ABI of libmiseg.so (declared in include/miseg.h) and the plan recorder/replayer.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace miseg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int launch_conv(const miseg_conv_desc* d, hipStream_t stream);
+int validate_conv(const miseg_conv_desc* d);
+int launch_prep_input(const float*, void*, const float*, const float*, int, int, int, hipStream_t);
+int launch_maxpool3x3s2(const void*, void*, const float*, const float*, int, int, int, int, int,
+                        int, hipStream_t);
+int launch_avgpool2x2(const void*, void*, int, int, int, int, int, int, hipStream_t);
+int launch_upsample_nearest(const void*, const void*, void*, int, int, int, int, int, int, int,
+                            int, hipStream_t);
+int launch_upsample_bilinear2x(const void*, void*, int, int, int, int, int, int, hipStream_t);
+int launch_scale_shift_relu(const void*, void*, const float*, const float*, long long, int, int,
+                            int, hipStream_t);
+int launch_collapse_u8(const float*, uint8_t*, long long, int, int, hipStream_t);
+int launch_loss_sums(const float*, const float*, double*, long long, int, hipStream_t);
+
+enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR };
+
+struct Op {
+  OpKind kind;
+  miseg_conv_desc conv;
+  const void* in;
+  const void* in2;
+  void* out;
+  const float* scale;
+  const float* shift;
+  long long pixels;
+  int N, H, W, C, shift_bits, ips, aps, ops;
+};
+
+static int run_op(const Op& o, hipStream_t s) {
+  switch (o.kind) {
+    case OP_CONV: return launch_conv(&o.conv, s);
+    case OP_PREP: return launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
+    case OP_MAXPOOL:
+      return launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_AVGPOOL: return launch_avgpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_UPNEAR:
+      return launch_upsample_nearest(o.in, o.in2, o.out, o.N, o.H, o.W, o.C, o.shift_bits, o.ips,
+                                     o.aps, o.ops, s);
+    case OP_UPBIL: return launch_upsample_bilinear2x(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_SSR:
+      return launch_scale_shift_relu(o.in, o.out, o.scale, o.shift, o.pixels, o.C, o.ips, o.ops, s);
+  }
+  set_error("plan: unknown op kind");
+  return MISEG_E_INVALID_ARG;
+}
+
+}  // namespace miseg
+
+struct miseg_plan {
+  std::vector<miseg::Op> ops;
+};
+
+using namespace miseg;
+
+extern "C" {
+
+const char* miseg_last_error(void) { return g_err; }
+
+int miseg_version(void) { return 100; }
+
+int miseg_device_check(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    set_error("no HIP device");
+    return MISEG_E_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    set_error("hipGetDeviceProperties failed");
+    return MISEG_E_NO_DEVICE;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
+    return MISEG_E_NO_DEVICE;
+  }
+  return MISEG_OK;
+}
+
+int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream) {
+  return launch_conv(d, (hipStream_t)stream);
+}
+
+int miseg_prep_input(const float* in, void* out, const float* scale, const float* shift, int32_t N,
+                     int32_t H, int32_t W, void* stream) {
+  return launch_prep_input(in, out, scale, shift, N, H, W, (hipStream_t)stream);
+}
+
+int miseg_maxpool3x3s2_fwd(const void* in, void* out, const float* scale, const float* shift,
+                           int32_t N, int32_t H, int32_t W, int32_t C, int32_t ips, int32_t ops,
+                           void* stream) {
+  return launch_maxpool3x3s2(in, out, scale, shift, N, H, W, C, ips, ops, (hipStream_t)stream);
+}
+
+int miseg_avgpool2x2_fwd(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t ips, int32_t ops, void* stream) {
+  return launch_avgpool2x2(in, out, N, H, W, C, ips, ops, (hipStream_t)stream);
+}
+
+int miseg_upsample_nearest_fwd(const void* in, const void* addend, void* out, int32_t N, int32_t H,
+                               int32_t W, int32_t C, int32_t shift, int32_t ips, int32_t aps,
+                               int32_t ops, void* stream) {
+  return launch_upsample_nearest(in, addend, out, N, H, W, C, shift, ips, aps, ops,
+                                 (hipStream_t)stream);
+}
+
+int miseg_upsample_bilinear2x_fwd(const void* in, void* out, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, int32_t ips, int32_t ops, void* stream) {
+  return launch_upsample_bilinear2x(in, out, N, H, W, C, ips, ops, (hipStream_t)stream);
+}
+
+int miseg_scale_shift_relu_fwd(const void* in, void* out, const float* scale, const float* shift,
+                               int64_t pixels, int32_t C, int32_t ips, int32_t ops, void* stream) {
+  return launch_scale_shift_relu(in, out, scale, shift, pixels, C, ips, ops, (hipStream_t)stream);
+}
+
+int miseg_collapse_u8(const float* probs, uint8_t* out, int64_t pixels, int32_t C, int32_t value,
+                      void* stream) {
+  return launch_collapse_u8(probs, out, pixels, C, value, (hipStream_t)stream);
+}
+
+int miseg_loss_sums(const float* gt, const float* pr, double* sums, int64_t pixels, int32_t C,
+                    void* stream) {
+  return launch_loss_sums(gt, pr, sums, pixels, C, (hipStream_t)stream);
+}
+
+// ---- plan ----
+miseg_plan* miseg_plan_create(void) { return new miseg_plan(); }
+void miseg_plan_destroy(miseg_plan* p) { delete p; }
+int miseg_plan_num_ops(const miseg_plan* p) { return p ? (int)p->ops.size() : 0; }
+
+int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  int rc = validate_conv(d);
+  if (rc != MISEG_OK) return rc;
+  Op o{};
+  o.kind = OP_CONV;
+  o.conv = *d;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
+int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
+                              const float* shift, int32_t N, int32_t H, int32_t W) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  Op o{};
+  o.kind = OP_PREP; o.in = in; o.out = out; o.scale = scale; o.shift = shift;
+  o.N = N; o.H = H; o.W = W;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
+int miseg_plan_add_maxpool3x3s2(miseg_plan* p, const void* in, void* out, const float* scale,
+                                const float* shift, int32_t N, int32_t H, int32_t W, int32_t C,
+                                int32_t ips, int32_t ops) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  Op o{};
+  o.kind = OP_MAXPOOL; o.in = in; o.out = out; o.scale = scale; o.shift = shift;
+  o.N = N; o.H = H; o.W = W; o.C = C; o.ips = ips; o.ops = ops;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
+int miseg_plan_add_avgpool2x2(miseg_plan* p, const void* in, void* out, int32_t N, int32_t H,
+                              int32_t W, int32_t C, int32_t ips, int32_t ops) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  Op o{};
+  o.kind = OP_AVGPOOL; o.in = in; o.out = out;
+  o.N = N; o.H = H; o.W = W; o.C = C; o.ips = ips; o.ops = ops;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
+int miseg_plan_add_upsample_nearest(miseg_plan* p, const void* in, const void* addend, void* out,
+                                    int32_t N, int32_t H, int32_t W, int32_t C, int32_t shift,
+                                    int32_t ips, int32_t aps, int32_t ops) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  Op o{};
+  o.kind = OP_UPNEAR; o.in = in; o.in2 = addend; o.out = out;
+  o.N = N; o.H = H; o.W = W; o.C = C; o.shift_bits = shift; o.ips = ips; o.aps = aps; o.ops = ops;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
+int miseg_plan_add_upsample_bilinear2x(miseg_plan* p, const void* in, void* out, int32_t N,
+                                       int32_t H, int32_t W, int32_t C, int32_t ips, int32_t ops) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  Op o{};
+  o.kind = OP_UPBIL; o.in = in; o.out = out;
+  o.N = N; o.H = H; o.W = W; o.C = C; o.ips = ips; o.ops = ops;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
+int miseg_plan_add_scale_shift_relu(miseg_plan* p, const void* in, void* out, const float* scale,
+                                    const float* shift, int64_t pixels, int32_t C, int32_t ips,
+                                    int32_t ops) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  Op o{};
+  o.kind = OP_SSR; o.in = in; o.out = out; o.scale = scale; o.shift = shift;
+  o.pixels = pixels; o.C = C; o.ips = ips; o.ops = ops;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
+int miseg_plan_run_range(const miseg_plan* p, int first, int last, void* stream, float* ms) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  MISEG_CHECK_ARG(first >= 0 && last <= (int)p->ops.size() && first <= last, "plan: bad op range");
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (ms) {
+    MISEG_CHECK_HIP(hipEventCreate(&e0));
+    MISEG_CHECK_HIP(hipEventCreate(&e1));
+    MISEG_CHECK_HIP(hipEventRecord(e0, s));
+  }
+  int rc = MISEG_OK;
+  for (int i = first; i < last && rc == MISEG_OK; ++i) rc = run_op(p->ops[i], s);
+  if (ms) {
+    hipError_t e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (rc == MISEG_OK && e != hipSuccess) {
+      set_error("plan timing failed: %s", hipGetErrorString(e));
+      rc = MISEG_E_HIP;
+    }
+  }
+  return rc;
+}
+
+int miseg_plan_run(const miseg_plan* p, void* stream) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  return miseg_plan_run_range(p, 0, (int)p->ops.size(), stream, nullptr);
+}
+
+int64_t miseg_plan_op_macs(const miseg_plan* p, int index) {
+  if (!p || index < 0 || index >= (int)p->ops.size()) return 0;
+  const Op& o = p->ops[index];
+  if (o.kind != OP_CONV) return 0;
+  const miseg_conv_desc& d = o.conv;
+  const int64_t per = (int64_t)d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin;
+  return d.transposed ? 4 * per : per;
+}
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+// Bandwidth-bound kernels around the convolutions (gfx950): input preparation, pooling,
+// upsampling, BatchNorm+ReLU application, probability collapse and the loss/metric sums.
+// All bf16 tensors are NHWC with a pixel stride (elements) so they can be channel slices
+// of wider buffers; every thread moves 16 bytes (8 bf16 channels) per access.
+#include "common.h"
+
+namespace miseg {
+
+static inline int grid_for(long long work, int block = 256) {
+  long long g = (work + block - 1) / block;
+  const long long cap = 256 * 16;  // grid-stride beyond ~16 blocks per CU
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------------------------
+// fp32 [N][H][W][3] -> bf16 [N][H+6][W+8][4], image at (3,3), zero elsewhere
+// ---------------------------------------------------------------------------------
+__global__ void prep_input_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  int N, int H, int W) {
+  const int Hp = H + 6, Wp = W + 8;
+  const long long total = (long long)N * Hp * Wp;
+  const float s0 = scale[0], s1 = scale[1], s2 = scale[2];
+  const float t0 = shift[0], t1 = shift[1], t2 = shift[2];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int xp = (int)(i % Wp);
+    const long long r = i / Wp;
+    const int yp = (int)(r % Hp);
+    const int n = (int)(r / Hp);
+    const int y = yp - 3, x = xp - 3;
+    uint2 v = make_uint2(0, 0);
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      const float* px = in + (((long long)n * H + y) * W + x) * 3;
+      v.x = pack_bf16x2(px[0] * s0 + t0, px[1] * s1 + t1);
+      v.y = pack_bf16x2(px[2] * s2 + t2, 0.f);
+    }
+    *reinterpret_cast<uint2*>(out + i * 4) = v;
+  }
+}
+
+int launch_prep_input(const float* in, void* out, const float* scale, const float* shift, int N,
+                      int H, int W, hipStream_t s) {
+  MISEG_CHECK_ARG(in && out && scale && shift, "prep_input: null pointer");
+  MISEG_CHECK_ARG(N > 0 && H > 0 && W > 0 && (W & 1) == 0 && (H & 1) == 0,
+                  "prep_input: H and W must be positive and even");
+  const long long total = (long long)N * (H + 6) * (W + 8);
+  hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, (bf16_t*)out,
+                     scale, shift, N, H, W);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// max pool 3x3 stride 2 after zero pad 1 (inputs are post-ReLU, so 0 == -inf padding)
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void max8(float (&m)[8], const uint4 v) {
+  m[0] = fmaxf(m[0], bf16lo_to_f32(v.x)); m[1] = fmaxf(m[1], bf16hi_to_f32(v.x));
+  m[2] = fmaxf(m[2], bf16lo_to_f32(v.y)); m[3] = fmaxf(m[3], bf16hi_to_f32(v.y));
+  m[4] = fmaxf(m[4], bf16lo_to_f32(v.z)); m[5] = fmaxf(m[5], bf16hi_to_f32(v.z));
+  m[6] = fmaxf(m[6], bf16lo_to_f32(v.w)); m[7] = fmaxf(m[7], bf16hi_to_f32(v.w));
+}
+__device__ __forceinline__ void unpack8(float (&m)[8], const uint4 v) {
+  m[0] = bf16lo_to_f32(v.x); m[1] = bf16hi_to_f32(v.x);
+  m[2] = bf16lo_to_f32(v.y); m[3] = bf16hi_to_f32(v.y);
+  m[4] = bf16lo_to_f32(v.z); m[5] = bf16hi_to_f32(v.z);
+  m[6] = bf16lo_to_f32(v.w); m[7] = bf16hi_to_f32(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&m)[8]) {
+  return make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]),
+                    pack_bf16x2(m[6], m[7]));
+}
+
+__global__ void maxpool3x3s2_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                    const float* __restrict__ scale,
+                                    const float* __restrict__ shift, int N, int H, int W, int C,
+                                    int ips, int ops) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int C8 = C >> 3;
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int y = 2 * oy - 1 + dy;
+      if ((unsigned)y >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int x = 2 * ox - 1 + dx;
+        if ((unsigned)x >= (unsigned)W) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(
+            in + (((long long)n * H + y) * W + x) * ips + c8 * 8);
+        max8(m, v);
+      }
+    }
+    if (scale) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j] * scale[c8 * 8 + j] + shift[c8 * 8 + j], 0.f);
+    }
+    *reinterpret_cast<uint4*>(out + (((long long)n * Ho + oy) * Wo + ox) * ops + c8 * 8) = pack8(m);
+  }
+}
+
+int launch_maxpool3x3s2(const void* in, void* out, const float* scale, const float* shift, int N,
+                        int H, int W, int C, int ips, int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(in && out, "maxpool: null pointer");
+  MISEG_CHECK_ARG((scale == nullptr) == (shift == nullptr), "maxpool: scale and shift go together");
+  MISEG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (ips & 7) == 0 &&
+                      (ops & 7) == 0 && ips >= C && ops >= C,
+                  "maxpool: C and strides must be multiples of 8");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in,
+                     (bf16_t*)out, scale, shift, N, H, W, C, ips, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// average pool 2x2 stride 2
+// ---------------------------------------------------------------------------------
+__global__ void avgpool2x2_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int N,
+                                  int H, int W, int C, int ips, int ops) {
+  const int Ho = H >> 1, Wo = W >> 1, C8 = C >> 3;
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float t[8];
+        unpack8(t, *reinterpret_cast<const uint4*>(
+                       in + (((long long)n * H + 2 * oy + dy) * W + 2 * ox + dx) * ips + c8 * 8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += t[j];
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= 0.25f;
+    *reinterpret_cast<uint4*>(out + (((long long)n * Ho + oy) * Wo + ox) * ops + c8 * 8) =
+        pack8(acc);
+  }
+}
+
+int launch_avgpool2x2(const void* in, void* out, int N, int H, int W, int C, int ips, int ops,
+                      hipStream_t s) {
+  MISEG_CHECK_ARG(in && out, "avgpool: null pointer");
+  MISEG_CHECK_ARG(N > 0 && H > 1 && W > 1 && C > 0 && (C & 7) == 0 && (ips & 7) == 0 &&
+                      (ops & 7) == 0 && ips >= C && ops >= C,
+                  "avgpool: C and strides must be multiples of 8");
+  const long long total = (long long)N * (H >> 1) * (W >> 1) * (C >> 3);
+  hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in,
+                     (bf16_t*)out, N, H, W, C, ips, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// nearest upsample by 2^shift, optional add
+// ---------------------------------------------------------------------------------
+__global__ void upsample_nearest_kernel(const bf16_t* __restrict__ in,
+                                        const bf16_t* __restrict__ addend,
+                                        bf16_t* __restrict__ out, int N, int H, int W, int C,
+                                        int shift, int ips, int aps, int ops) {
+  const int Ho = H << shift, Wo = W << shift, C8 = C >> 3;
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    uint4 v = *reinterpret_cast<const uint4*>(
+        in + (((long long)n * H + (oy >> shift)) * W + (ox >> shift)) * ips + c8 * 8);
+    const long long opix = ((long long)n * Ho + oy) * Wo + ox;
+    if (addend) {
+      float a[8], b[8];
+      unpack8(a, v);
+      unpack8(b, *reinterpret_cast<const uint4*>(addend + opix * aps + c8 * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += b[j];
+      v = pack8(a);
+    }
+    *reinterpret_cast<uint4*>(out + opix * ops + c8 * 8) = v;
+  }
+}
+
+int launch_upsample_nearest(const void* in, const void* addend, void* out, int N, int H, int W,
+                            int C, int shift, int ips, int aps, int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(in && out, "upsample_nearest: null pointer");
+  MISEG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (ips & 7) == 0 &&
+                      (ops & 7) == 0 && (!addend || (aps & 7) == 0) && shift >= 0 && shift <= 4,
+                  "upsample_nearest: C and strides must be multiples of 8, shift in 0..4");
+  const long long total = ((long long)N * (H << shift) * (W << shift)) * (C >> 3);
+  hipLaunchKernelGGL(upsample_nearest_kernel, dim3(grid_for(total)), dim3(256), 0, s,
+                     (const bf16_t*)in, (const bf16_t*)addend, (bf16_t*)out, N, H, W, C, shift, ips,
+                     aps, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// bilinear x2, half-pixel centres: src = (dst + 0.5)/2 - 0.5 clamped to [0, n-1]
+// ---------------------------------------------------------------------------------
+__global__ void upsample_bilinear2x_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                           int N, int H, int W, int C, int ips, int ops) {
+  const int Ho = 2 * H, Wo = 2 * W, C8 = C >> 3;
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float sy = fminf(fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.f), (float)(H - 1));
+    float sx = fminf(fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.f), (float)(W - 1));
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    const float fy = sy - y0, fx = sx - x0;
+    const bf16_t* base = in + (long long)n * H * W * ips + c8 * 8;
+    float a[8], b[8], c[8], d[8], o[8];
+    unpack8(a, *reinterpret_cast<const uint4*>(base + ((long long)y0 * W + x0) * ips));
+    unpack8(b, *reinterpret_cast<const uint4*>(base + ((long long)y0 * W + x1) * ips));
+    unpack8(c, *reinterpret_cast<const uint4*>(base + ((long long)y1 * W + x0) * ips));
+    unpack8(d, *reinterpret_cast<const uint4*>(base + ((long long)y1 * W + x1) * ips));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float top = a[j] * (1.f - fx) + b[j] * fx;
+      const float bot = c[j] * (1.f - fx) + d[j] * fx;
+      o[j] = top * (1.f - fy) + bot * fy;
+    }
+    *reinterpret_cast<uint4*>(out + (((long long)n * Ho + oy) * Wo + ox) * ops + c8 * 8) = pack8(o);
+  }
+}
+
+int launch_upsample_bilinear2x(const void* in, void* out, int N, int H, int W, int C, int ips,
+                               int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(in && out, "upsample_bilinear2x: null pointer");
+  MISEG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (ips & 7) == 0 &&
+                      (ops & 7) == 0,
+                  "upsample_bilinear2x: C and strides must be multiples of 8");
+  const long long total = (long long)N * 4 * H * W * (C >> 3);
+  hipLaunchKernelGGL(upsample_bilinear2x_kernel, dim3(grid_for(total)), dim3(256), 0, s,
+                     (const bf16_t*)in, (bf16_t*)out, N, H, W, C, ips, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// y = relu(x*scale + shift)
+// ---------------------------------------------------------------------------------
+__global__ void scale_shift_relu_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                        const float* __restrict__ scale,
+                                        const float* __restrict__ shift, long long pixels, int C,
+                                        int ips, int ops) {
+  const int C8 = C >> 3;
+  const long long total = pixels * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    const long long pix = i / C8;
+    float a[8];
+    unpack8(a, *reinterpret_cast<const uint4*>(in + pix * ips + c8 * 8));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = fmaxf(a[j] * scale[c8 * 8 + j] + shift[c8 * 8 + j], 0.f);
+    *reinterpret_cast<uint4*>(out + pix * ops + c8 * 8) = pack8(a);
+  }
+}
+
+int launch_scale_shift_relu(const void* in, void* out, const float* scale, const float* shift,
+                            long long pixels, int C, int ips, int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(in && out && scale && shift, "scale_shift_relu: null pointer");
+  MISEG_CHECK_ARG(pixels > 0 && C > 0 && (C & 7) == 0 && (ips & 7) == 0 && (ops & 7) == 0,
+                  "scale_shift_relu: C and strides must be multiples of 8");
+  hipLaunchKernelGGL(scale_shift_relu_kernel, dim3(grid_for(pixels * (C >> 3))), dim3(256), 0, s,
+                     (const bf16_t*)in, (bf16_t*)out, scale, shift, pixels, C, ips, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// collapse_probabilities: channels decided in order against already-collapsed values
+// ---------------------------------------------------------------------------------
+__global__ void collapse_u8_kernel(const float* __restrict__ probs, uint8_t* __restrict__ out,
+                                   long long pixels, int C, float value) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pixels;
+       i += (long long)gridDim.x * blockDim.x) {
+    float p[8], cv[8];
+    for (int j = 0; j < C; ++j) p[j] = probs[i * C + j];
+    for (int a = 0; a < C; ++a) {
+      bool win = true;
+      for (int j = 0; j < C; ++j) {
+        if (j == a) continue;
+        const float other = j < a ? cv[j] : p[j];
+        win = win && (p[a] > other);
+      }
+      cv[a] = win ? value : 0.f;
+    }
+    for (int j = 0; j < C; ++j) out[i * C + j] = (uint8_t)cv[j];
+  }
+}
+
+int launch_collapse_u8(const float* probs, uint8_t* out, long long pixels, int C, int value,
+                       hipStream_t s) {
+  MISEG_CHECK_ARG(probs && out, "collapse: null pointer");
+  MISEG_CHECK_ARG(pixels > 0 && C >= 1 && C <= 8 && value >= 0 && value <= 255,
+                  "collapse: need 1 <= C <= 8 and 0 <= value <= 255");
+  hipLaunchKernelGGL(collapse_u8_kernel, dim3(grid_for(pixels)), dim3(256), 0, s, probs, out,
+                     pixels, C, (float)value);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// loss / metric sums: per class sum(gt*pr), sum(pr), sum(gt), sum(gt*log(clip(pr/sum pr)))
+// ---------------------------------------------------------------------------------
+template <int C>
+__global__ void loss_sums_kernel(const float* __restrict__ gt, const float* __restrict__ pr,
+                                 double* __restrict__ sums, long long pixels) {
+  float acc[4 * C];
+#pragma unroll
+  for (int j = 0; j < 4 * C; ++j) acc[j] = 0.f;
+  // per-thread fp32 partials over at most a few thousand pixels, then fp64 atomics
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pixels;
+       i += (long long)gridDim.x * blockDim.x) {
+    float g[C], p[C], s = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      g[j] = gt[i * C + j];
+      p[j] = pr[i * C + j];
+      s += p[j];
+    }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      const float q = fminf(fmaxf(p[j] * inv, 1e-7f), 1.f - 1e-7f);
+      acc[j] += g[j] * p[j];
+      acc[C + j] += p[j];
+      acc[2 * C + j] += g[j];
+      acc[3 * C + j] += g[j] * __logf(q);
+    }
+  }
+  __shared__ double red[4 * C];
+  if (threadIdx.x < 4 * C) red[threadIdx.x] = 0.0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4 * C; ++j) {
+    float v = acc[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&red[j], (double)v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4 * C) atomicAdd(&sums[threadIdx.x], red[threadIdx.x]);
+}
+
+int launch_loss_sums(const float* gt, const float* pr, double* sums, long long pixels, int C,
+                     hipStream_t s) {
+  MISEG_CHECK_ARG(gt && pr && sums, "loss_sums: null pointer");
+  MISEG_CHECK_ARG(pixels > 0 && C >= 1 && C <= 8, "loss_sums: need 1 <= C <= 8");
+  MISEG_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 4 * C, s));
+  const dim3 grid(grid_for(pixels)), block(256);
+  switch (C) {
+    case 1: hipLaunchKernelGGL(loss_sums_kernel<1>, grid, block, 0, s, gt, pr, sums, pixels); break;
+    case 2: hipLaunchKernelGGL(loss_sums_kernel<2>, grid, block, 0, s, gt, pr, sums, pixels); break;
+    case 3: hipLaunchKernelGGL(loss_sums_kernel<3>, grid, block, 0, s, gt, pr, sums, pixels); break;
+    case 4: hipLaunchKernelGGL(loss_sums_kernel<4>, grid, block, 0, s, gt, pr, sums, pixels); break;
+    case 5: hipLaunchKernelGGL(loss_sums_kernel<5>, grid, block, 0, s, gt, pr, sums, pixels); break;
+    case 6: hipLaunchKernelGGL(loss_sums_kernel<6>, grid, block, 0, s, gt, pr, sums, pixels); break;
+    case 7: hipLaunchKernelGGL(loss_sums_kernel<7>, grid, block, 0, s, gt, pr, sums, pixels); break;
+    default: hipLaunchKernelGGL(loss_sums_kernel<8>, grid, block, 0, s, gt, pr, sums, pixels); break;
+  }
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+}  // namespace miseg

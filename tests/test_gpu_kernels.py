@@ -1,0 +1,343 @@
+"""Parity of each HIP kernel, called through the C ABI, against the CPU oracle
+(oracle/ops_np.py, oracle/ops_torch.py) on seeded inputs.  Inputs and weights
+are rounded to bf16 first, so the oracle sees exactly the operands the kernels
+see and the remaining difference is fp32 accumulation order plus the bf16
+rounding of the stored result (tolerances stated per test)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+
+@pytest.fixture(scope="module")
+def env():
+    import miseg_amd
+    from miseg_amd import lib as L
+    lib = L.load()
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    L.check(lib.miseg_device_check())
+    return L, lib, torch.device("cuda:0")
+
+
+def dev_bf16(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(dev)
+
+
+def dev_f32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+
+
+def run_conv(env, x, w_hwio, stride=1, pad=0, scale=None, shift=None, act=0, residual=None,
+             res_f32=True, scale2=None, shift2=None, in_scale=None, in_shift=None, out_f32=False,
+             want_out=True, tile_hint=0, in_extra_c=0, out_extra_c=0):
+    """x: (N,H,W,Cin) fp32 (bf16-representable); returns (out, out2) as fp32 numpy."""
+    L, lib, dev = env
+    n, h, wd, cin = x.shape
+    kh, kw, _, cout = w_hwio.shape
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (wd + 2 * pad - kw) // stride + 1
+    xin = torch.zeros((n, h, wd, cin + in_extra_c), dtype=torch.bfloat16, device=dev)
+    xin[..., in_extra_c:] = dev_bf16(x, dev)
+    wt = dev_bf16(w_hwio.transpose(3, 0, 1, 2), dev)
+    out = torch.full((n, ho, wo, cout + out_extra_c), 7.0,
+                     dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev)
+    out2 = torch.full((n, ho, wo, cout), 7.0, dtype=torch.bfloat16, device=dev)
+    keep = []
+
+    def f32p(a):
+        if a is None:
+            return None
+        t = dev_f32(a, dev)
+        keep.append(t)
+        return t.data_ptr()
+
+    d = L.ConvDesc()
+    d.inp = xin.data_ptr() + 2 * in_extra_c
+    d.weight = wt.data_ptr()
+    d.N, d.H, d.W, d.Cin = n, h, wd, cin
+    d.Ho, d.Wo, d.Cout = ho, wo, cout
+    d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, stride, stride, pad, pad
+    cs = cin + in_extra_c
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = cs, cs * wd, cs * wd * h
+    if want_out:
+        d.out = out.data_ptr() + out_extra_c * out.element_size()
+        co = cout + out_extra_c
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = co, co * wo, co * wo * ho
+    d.out_dtype = L.DT_F32 if out_f32 else L.DT_BF16
+    if scale2 is not None:
+        d.out2 = out2.data_ptr()
+        d.out2_pix_stride, d.out2_row_stride, d.out2_img_stride = cout, cout * wo, cout * wo * ho
+        d.scale2, d.shift2 = f32p(scale2), f32p(shift2)
+    if residual is not None:
+        r = dev_f32(residual, dev) if res_f32 else dev_bf16(residual, dev)
+        keep.append(r)
+        d.residual = r.data_ptr()
+        d.res_dtype = L.DT_F32 if res_f32 else L.DT_BF16
+        d.res_pix_stride, d.res_row_stride, d.res_img_stride = cout, cout * wo, cout * wo * ho
+    d.scale, d.shift = f32p(scale), f32p(shift)
+    d.in_scale, d.in_shift = f32p(in_scale), f32p(in_shift)
+    d.act = act
+    d.temperature = 1.0
+    d.tile_hint = tile_hint
+    L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+    torch.cuda.synchronize()
+    o = out[..., out_extra_c:].float().cpu().numpy() if want_out else None
+    o2 = out2.float().cpu().numpy() if scale2 is not None else None
+    if out_extra_c and want_out:
+        assert torch.all(out[..., :out_extra_c].float() == 7.0), "wrote outside its channel slice"
+    return o, o2
+
+
+def ref_conv(x, w, stride, pad, in_scale=None, in_shift=None):
+    from oracle import ops_torch as T
+    xt = T.asarray(x)
+    if in_scale is not None:
+        xt = torch.relu(xt * torch.from_numpy(in_scale) + torch.from_numpy(in_shift))
+        xt = xt.to(torch.bfloat16).float()     # the kernel re-rounds the activated operand
+    return T.to_numpy(T.conv2d(xt, w, stride=stride, pad=pad))
+
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, pad
+    (1, 12, 20, 32, 32, 3, 1, 1),
+    (2, 9, 13, 64, 64, 3, 1, 1),       # odd sizes, M tail
+    (1, 16, 24, 64, 128, 3, 2, 1),     # stride 2, symmetric pad
+    (1, 16, 16, 96, 160, 1, 1, 0),     # cout not a tile multiple
+    (1, 10, 14, 32, 64, 1, 2, 0),      # shortcut conv
+    (1, 8, 8, 128, 256, 3, 1, 1),
+    (1, 20, 12, 32, 8, 3, 1, 1),       # narrow cout
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7])
+def test_conv_plain(env, case, hint):
+    n, h, w, cin, cout, k, stride, pad = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    wt = bf16_round(rng.normal(0, 0.1, (k, k, cin, cout)))
+    got, _ = run_conv(env, x, wt, stride, pad, out_f32=True, tile_hint=hint)
+    want = ref_conv(x, wt, stride, pad)
+    # fp32 accumulation of identical bf16 operands: only summation order differs
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
+def test_conv_epilogues(env):
+    rng = np.random.default_rng(7)
+    n, h, w, cin, cout = 2, 10, 12, 64, 64
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    wt = bf16_round(rng.normal(0, 0.1, (3, 3, cin, cout)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.5, cout).astype(np.float32)
+    base = ref_conv(x, wt, 1, 1)
+    # scale/shift/relu, bf16 output inside a wider buffer (concat slice)
+    got, _ = run_conv(env, x, wt, 1, 1, scale=sc, shift=sh, act=1, in_extra_c=32, out_extra_c=64)
+    want = np.maximum(base * sc + sh, 0)
+    np.testing.assert_allclose(got, want, rtol=1e-2, atol=1e-2)   # bf16 store: 2^-8 relative
+    # residual (fp32) + raw fp32 output + activated second output
+    res = rng.normal(0, 1, (n, h, w, cout)).astype(np.float32)
+    s2 = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    t2 = rng.normal(0, 0.5, cout).astype(np.float32)
+    got, got2 = run_conv(env, x, wt, 1, 1, residual=res, scale2=s2, shift2=t2, out_f32=True)
+    np.testing.assert_allclose(got, base + res, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(got2, np.maximum((base + res) * s2 + t2, 0), rtol=1e-2, atol=1e-2)
+    # second output only, bf16 residual
+    resb = bf16_round(res)
+    _, got2 = run_conv(env, x, wt, 1, 1, residual=resb, res_f32=False, scale2=s2, shift2=t2,
+                       want_out=False)
+    np.testing.assert_allclose(got2, np.maximum((base + resb) * s2 + t2, 0), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("k,pad", [(1, 0), (3, 1)])
+def test_conv_prologue(env, k, pad):
+    """BatchNorm+ReLU applied to the operand; padded taps must stay zero."""
+    rng = np.random.default_rng(11)
+    n, h, w, cin, cout = 1, 9, 11, 96, 128
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    wt = bf16_round(rng.normal(0, 0.1, (k, k, cin, cout)))
+    s = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    t = rng.normal(0.3, 0.5, cin).astype(np.float32)    # positive shift: relu(shift) != 0
+    got, _ = run_conv(env, x, wt, 1, pad, in_scale=s, in_shift=t, out_f32=True)
+    want = ref_conv(x, wt, 1, pad, in_scale=s, in_shift=t)
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3 * np.abs(want).max())
+
+
+def test_conv_transpose_4x4s2(env):
+    from oracle import ops_np, ops_torch
+    L, lib, dev = env
+    rng = np.random.default_rng(3)
+    n, h, w, cin, cout = 2, 6, 7, 64, 32
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    k = bf16_round(rng.normal(0, 0.1, (4, 4, cout, cin)))      # Keras layout
+    want = ops_np.conv2d_transpose_4x4s2(x, k)
+    want_t = ops_torch.to_numpy(ops_torch.conv2d_transpose_4x4s2(ops_torch.asarray(x), k))
+    np.testing.assert_allclose(want, want_t, rtol=1e-4, atol=1e-4)
+    ph = np.zeros((2, 2, cout, 2, 2, cin), np.float32)
+    for a in range(2):
+        for b in range(2):
+            for dy in range(2):
+                for dx in range(2):
+                    ph[a, b, :, dy, dx, :] = k[3 - a - 2 * dy, 3 - b - 2 * dx]
+    xin, wt = dev_bf16(x, dev), dev_bf16(ph, dev)
+    out = torch.zeros((n, 2 * h, 2 * w, cout), dtype=torch.float32, device=dev)
+    d = L.ConvDesc()
+    d.inp, d.weight, d.out = xin.data_ptr(), wt.data_ptr(), out.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, h, w, cout
+    d.KH = d.KW = 2
+    d.stride_y = d.stride_x = 1
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin, cin * w, cin * w * h
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * 2 * w, cout * 4 * w * h
+    d.out_dtype, d.transposed, d.temperature = L.DT_F32, 1, 1.0
+    L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("classes,act", [(3, 2), (4, 2), (1, 3), (2, 2)])
+def test_conv_head_softmax_collapse(env, classes, act):
+    """3x3 head + bias + softmax/sigmoid + strict-argmax collapse in the epilogue."""
+    from oracle import ops_np, post
+    L, lib, dev = env
+    rng = np.random.default_rng(5)
+    n, h, w, cin = 2, 10, 12, 32
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    k = bf16_round(rng.normal(0, 0.2, (3, 3, cin, classes)))
+    bias = rng.normal(0, 0.1, classes).astype(np.float32)
+    logits = ops_np.conv2d(x, k, pad=1, bias=bias)
+    temp = 0.5
+    want = ops_np.softmax(logits, temp) if act == 2 else ops_np.sigmoid(logits)
+    xin, wt = dev_bf16(x, dev), dev_bf16(k.transpose(3, 0, 1, 2), dev)
+    out = torch.zeros((n, h, w, classes), dtype=torch.float32, device=dev)
+    mask = torch.zeros((n, h, w, classes), dtype=torch.uint8, device=dev)
+    b = dev_f32(bias, dev)
+    d = L.ConvDesc()
+    d.inp, d.weight, d.out, d.shift = xin.data_ptr(), wt.data_ptr(), out.data_ptr(), b.data_ptr()
+    d.collapse_out = mask.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, h, w, classes
+    d.KH = d.KW = 3
+    d.stride_y = d.stride_x = d.pad_y = d.pad_x = 1
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin, cin * w, cin * w * h
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = classes, classes * w, classes * w * h
+    d.out_dtype, d.act, d.temperature, d.collapse_value = L.DT_F32, act, temp, 127
+    L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5)
+    # the mask must be the reference collapse of the probabilities the kernel itself produced
+    want_mask = np.stack([post.collapse_probabilities(got[i], 127) for i in range(n)])
+    np.testing.assert_array_equal(mask.cpu().numpy(), want_mask)
+
+
+def test_prep_input_and_stem(env):
+    """bn_data + ZeroPadding2D(3) + 7x7/2 stem conv via the channel-padded 7x1 form."""
+    from oracle import ops_np
+    L, lib, dev = env
+    rng = np.random.default_rng(9)
+    n, h, w = 2, 32, 64
+    x = rng.uniform(0, 1, (n, h, w, 3)).astype(np.float32)
+    s = rng.uniform(0.5, 2, 3).astype(np.float32)
+    t = rng.normal(0, 0.3, 3).astype(np.float32)
+    k = bf16_round(rng.normal(0, 0.1, (7, 7, 3, 64)))
+    xd = dev_f32(x, dev)
+    padded = torch.full((n, h + 6, w + 8, 4), 5.0, dtype=torch.bfloat16, device=dev)
+    sd, td = dev_f32(s, dev), dev_f32(t, dev)
+    L.check(lib.miseg_prep_input(xd.data_ptr(), padded.data_ptr(), sd.data_ptr(), td.data_ptr(),
+                                 n, h, w, None))
+    torch.cuda.synchronize()
+    p = padded.float().cpu().numpy()
+    # the kernel contracts x*s+t into one fma, numpy rounds twice: allow one bf16 ulp
+    np.testing.assert_allclose(p[:, 3:3 + h, 3:3 + w, :3], bf16_round(x * s + t), rtol=2 ** -7, atol=1e-6)
+    xb = p[:, 3:3 + h, 3:3 + w, :3].copy()
+    assert p[:, :3].max() == 0 and p[:, 3 + h:].max() == 0 and p[..., 3].max() == 0
+    assert np.abs(p[:, :, :3]).max() == 0 and np.abs(p[:, :, 3 + w:]).max() == 0
+    wk = np.zeros((64, 7, 1, 8, 4), np.float32)
+    wk[:, :, 0, :7, :3] = k.transpose(3, 0, 1, 2)
+    wt = dev_bf16(wk.reshape(64, 7, 1, 32), dev)
+    out = torch.zeros((n, h // 2, w // 2, 64), dtype=torch.float32, device=dev)
+    d = L.ConvDesc()
+    d.inp, d.weight, d.out = padded.data_ptr(), wt.data_ptr(), out.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h + 6, w // 2, 32, h // 2, w // 2, 64
+    d.KH, d.KW, d.stride_y, d.stride_x = 7, 1, 2, 1
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = 8, (w + 8) * 4, (h + 6) * (w + 8) * 4
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = 64, 64 * (w // 2), 64 * (w // 2) * (h // 2)
+    d.out_dtype, d.temperature = L.DT_F32, 1.0
+    L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+    torch.cuda.synchronize()
+    want = ops_np.conv2d(xb, k, stride=2, pad=3)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+
+
+def test_pointwise_kernels(env):
+    from oracle import ops_np
+    L, lib, dev = env
+    rng = np.random.default_rng(13)
+    n, h, w, c = 2, 12, 20, 40
+    x = bf16_round(np.abs(rng.normal(0, 1, (n, h, w, c))))
+    xd = dev_bf16(x, dev)
+    # max pool (+ scale/shift/relu)
+    s = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    t = rng.normal(0, 0.5, c).astype(np.float32)
+    out = torch.zeros((n, h // 2, w // 2, c), dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_maxpool3x3s2_fwd(xd.data_ptr(), out.data_ptr(), None, None, n, h, w, c, c, c, None))
+    np.testing.assert_array_equal(out.float().cpu().numpy(), ops_np.maxpool3x3s2_pad1(x))
+    sd, td = dev_f32(s, dev), dev_f32(t, dev)
+    L.check(lib.miseg_maxpool3x3s2_fwd(xd.data_ptr(), out.data_ptr(), sd.data_ptr(), td.data_ptr(),
+                                       n, h, w, c, c, c, None))
+    np.testing.assert_array_equal(out.float().cpu().numpy(),
+                                  bf16_round(np.maximum(ops_np.maxpool3x3s2_pad1(x) * s + t, 0)))
+    # average pool
+    L.check(lib.miseg_avgpool2x2_fwd(xd.data_ptr(), out.data_ptr(), n, h, w, c, c, c, None))
+    np.testing.assert_allclose(out.float().cpu().numpy(), ops_np.avgpool2x2(x), rtol=1e-2, atol=1e-3)
+    # nearest upsample x4, and x2 + add
+    up = torch.zeros((n, 4 * h, 4 * w, c), dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_upsample_nearest_fwd(xd.data_ptr(), None, up.data_ptr(), n, h, w, c, 2, c, 0, c, None))
+    np.testing.assert_array_equal(up.float().cpu().numpy(), ops_np.upsample_nearest(x, 4))
+    y = bf16_round(rng.normal(0, 1, (n, 2 * h, 2 * w, c)))
+    yd = dev_bf16(y, dev)
+    L.check(lib.miseg_upsample_nearest_fwd(xd.data_ptr(), yd.data_ptr(), yd.data_ptr(), n, h, w, c, 1, c, c, c, None))
+    np.testing.assert_array_equal(yd.float().cpu().numpy(), bf16_round(ops_np.upsample_nearest(x, 2) + y))
+    # bilinear x2
+    up2 = torch.zeros((n, 2 * h, 2 * w, c), dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_upsample_bilinear2x_fwd(xd.data_ptr(), up2.data_ptr(), n, h, w, c, c, c, None))
+    np.testing.assert_allclose(up2.float().cpu().numpy(), ops_np.upsample_bilinear2x(x), rtol=1e-2, atol=1e-3)
+    # scale/shift/relu
+    o = torch.zeros_like(xd)
+    L.check(lib.miseg_scale_shift_relu_fwd(xd.data_ptr(), o.data_ptr(), sd.data_ptr(), td.data_ptr(),
+                                           n * h * w, c, c, c, None))
+    np.testing.assert_array_equal(o.float().cpu().numpy(), bf16_round(np.maximum(x * s + t, 0)))
+    torch.cuda.synchronize()
+
+
+def test_collapse_and_loss_sums(env):
+    from oracle import losses, post
+    L, lib, dev = env
+    rng = np.random.default_rng(17)
+    h, w, c = 40, 50, 3
+    p = rng.dirichlet(np.ones(c), size=(h, w)).astype(np.float32)
+    p[0, 0] = (0.5, 0.5, 0.0)        # ties: the in-place loop gives (0,127,0)
+    p[0, 1] = (0.25, 0.25, 0.5)
+    p[0, 2] = (1 / 3, 1 / 3, 1 / 3)
+    p[0, 3] = (0.4, 0.2, 0.4)
+    pd = dev_f32(p, dev)
+    out = torch.zeros((h, w, c), dtype=torch.uint8, device=dev)
+    L.check(lib.miseg_collapse_u8(pd.data_ptr(), out.data_ptr(), h * w, c, 127, None))
+    np.testing.assert_array_equal(out.cpu().numpy(), post.collapse_probabilities(p, 127))
+    gt = post.one_hot_encode(rng.integers(0, c, (h, w, 1)), c)
+    gd = dev_f32(gt, dev)
+    sums = torch.zeros(4 * c, dtype=torch.float64, device=dev)
+    L.check(lib.miseg_loss_sums(gd.data_ptr(), pd.data_ptr(), sums.data_ptr(), h * w, c, None))
+    s = sums.cpu().numpy().reshape(4, c)
+    tp, spr, sgt, sl = s
+    f1 = np.mean((2 * tp + 1e-5) / (spr + sgt + 1e-5))
+    iou = np.mean((tp + 1e-5) / (spr + sgt - tp + 1e-5))
+    cce = -sl.sum() / (h * w * c)
+    assert abs(f1 - losses.f1_score(gt[None], p[None])) < 1e-5
+    assert abs(iou - losses.iou_score(gt[None], p[None])) < 1e-5
+    assert abs(cce + 1 - f1 - losses.cce_dice_loss(gt[None], p[None])) < 1e-5
