@@ -42,6 +42,8 @@ extern "C" {
 #define MISEG_ACT_SOFTMAX 2 /* over Cout (<= 4), fp32 output, optional u8 collapse */
 #define MISEG_ACT_SIGMOID 3
 
+#define MISEG_TILE_NO_DMA 16
+
 const char* miseg_last_error(void);
 int miseg_version(void);
 /* 0 if the current HIP device is a gfx950; MISEG_E_NO_DEVICE otherwise. */
@@ -100,7 +102,8 @@ typedef struct miseg_conv_desc {
   int32_t transposed;
   float temperature;       /* MISEG_ACT_SOFTMAX: logits are divided by it */
   int32_t collapse_value;  /* value written for the winning channel (127) */
-  int32_t tile_hint;       /* 0 = choose automatically */
+  int32_t tile_hint;       /* 0 = choose automatically; low 4 bits = tile config 1..7,
+                              | MISEG_TILE_NO_DMA forces the register-staged path (tests) */
 } miseg_conv_desc;
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);

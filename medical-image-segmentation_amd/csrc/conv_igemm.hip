@@ -10,12 +10,10 @@
 // each lane ends up with runs of 4 consecutive output channels of one pixel
 // (NHWC-contiguous) in its accumulator registers.
 //
-// Block = 256 threads = 4 waves.  Per K-step (one tap x 32 input channels) the block
-// stages a [BM pixels][32] and a [BN couts][32] bf16 tile through registers into
-// double-buffered LDS (one barrier per K-step, next tile's global loads issued before
-// the current tile's MFMAs).  Rows are 64 B; the 16-B chunk index is XOR-swizzled with
-// row bits 2..3 so ds_read_b128 fragment reads and ds_write_b128 staging writes are
-// bank-conflict free.
+// Block = 256 threads = 4 waves; a K-step is one filter tap x BK input channels of a
+// [BM pixels] x [BN couts] tile, double-buffered in LDS with one barrier per K-step.
+// Two staging paths: LDS-DMA (global_load_lds, BK = 64) for plain bf16 operands, and a
+// register-staged path (BK = 32) that can apply BatchNorm+ReLU to the operand on the way.
 #include "common.h"
 
 namespace miseg {
@@ -53,12 +51,270 @@ struct ConvParams {
   int M;        // N*Ho*Wo
   int mtiles;   // ceil(M / BM)
   int ntiles;   // ceil(Cout / BN)
+  int vec_ok;   // strides/pointers allow 16-byte epilogue accesses
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) {
+// 16 zero bytes x 8: the source of LDS-DMA loads for taps that fall outside the image.
+__device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];
+
+// LDS tile addressing.  Rows of 64 B (BK=32) hold 4 sixteen-byte chunks, rows of 128 B
+// (BK=64) hold 8; the chunk index is XOR-swizzled with row bits so that the 16 rows a
+// ds_read_b128 lane group touches land on 16 distinct 16-B slots of the 256-B bank row.
+__device__ __forceinline__ int swz64(int row, int chunk) {
   return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
 }
+__device__ __forceinline__ int swz128(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
 
+struct TileCoord {
+  int m0, cout0, ph_a, ph_b, pad_y, pad_x;
+  const bf16_t* wbase;
+};
+
+template <int BM, int BN>
+__device__ __forceinline__ TileCoord tile_coord(const ConvParams& p) {
+  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each of the 8
+  // groups a contiguous run of tiles, with the N-tiles of one M-tile adjacent.
+  TileCoord t;
+  const int ntot = p.mtiles * p.ntiles;
+  const int bid = blockIdx.x;
+  const int q = ntot >> 3, r = ntot & 7;
+  const int x = bid & 7, loc = bid >> 3;
+  const int tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+  const int mtile = tile / p.ntiles;
+  const int ntile = tile - mtile * p.ntiles;
+  t.m0 = mtile * BM;
+  t.cout0 = ntile * BN;
+  t.pad_y = p.pad_y;
+  t.pad_x = p.pad_x;
+  t.ph_a = t.ph_b = 0;
+  t.wbase = p.weight;
+  if (p.transposed) {
+    const int phase = blockIdx.y;
+    t.ph_a = phase >> 1;
+    t.ph_b = phase & 1;
+    t.pad_y = 1 - t.ph_a;
+    t.pad_x = 1 - t.ph_b;
+    t.wbase += (long long)phase * p.Cout * 4 * p.Cin;
+  }
+  return t;
+}
+
+// ---------------------------------------------------------------------------------
+// Epilogue.  The accumulators hold D[cout][pixel]; each wave transposes one 32-pixel
+// tile at a time through its own LDS region ([32 pixels][NT*32 couts] fp32, rows padded
+// by 16 B) so that every lane then owns 8 consecutive output channels of one pixel:
+// 16-byte bf16 stores (32-byte fp32), residual loads of the same shape, and the
+// channels of a pixel written by adjacent lanes.
+// ---------------------------------------------------------------------------------
+template <int WARPS_N, int MT, int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoord& tc,
+                                              f32x16 (&acc)[NT][MT], unsigned char* lds, int wm,
+                                              int wn, int lane) {
+  constexpr int TNW = NT * 32;       // couts per wave tile
+  constexpr int ROWF = TNW + 4;      // floats per LDS row
+  constexpr int LPP = TNW / 8;       // lanes per pixel when reading back
+  constexpr int PPP = 64 / LPP;      // pixels per pass
+  constexpr int PASSES = 32 / PPP;
+  const int wave = wm * WARPS_N + wn;
+  float* ep = reinterpret_cast<float*>(lds) + wave * (32 * ROWF);
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  const int HoWo = p.Ho * p.Wo;
+  const bool has_res = p.residual != nullptr;
+  const int px_l = lane / LPP;
+  const int co_l = (lane % LPP) * 8;
+  const int co = tc.cout0 + wn * TNW + co_l;
+  const bool co_any = co < p.Cout;
+  const bool full = co + 8 <= p.Cout && p.vec_ok;
+
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(ep + lrow * ROWF + a * 32 + 8 * g + 4 * lhalf) =
+            make_float4(acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2],
+                        acc[a][b][4 * g + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int px = ps * PPP + px_l;
+      const int m = tc.m0 + wm * (MT * 32) + b * 32 + px;
+      if (m >= p.M || !co_any) continue;
+      const int n = m / HoWo;
+      const int rem = m - n * HoWo;
+      int oy = rem / p.Wo;
+      int ox = rem - oy * p.Wo;
+      if (p.transposed) {
+        oy = 2 * oy + tc.ph_a;
+        ox = 2 * ox + tc.ph_b;
+      }
+      float v[8];
+      {
+        const float4 v0 = *reinterpret_cast<const float4*>(ep + px * ROWF + co_l);
+        const float4 v1 = *reinterpret_cast<const float4*>(ep + px * ROWF + co_l + 4);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
+        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+      }
+      const long long o_off = n * p.out_img_stride + (long long)oy * p.out_row_stride +
+                              (long long)ox * p.out_pix_stride + co;
+      const long long o2_off = n * p.out2_img_stride + (long long)oy * p.out2_row_stride +
+                               (long long)ox * p.out2_pix_stride + co;
+      const long long r_off = n * p.res_img_stride + (long long)oy * p.res_row_stride +
+                              (long long)ox * p.res_pix_stride + co;
+      if (full) {
+        if (p.scale) {
+          const float4 s0 = *reinterpret_cast<const float4*>(p.scale + co);
+          const float4 s1 = *reinterpret_cast<const float4*>(p.scale + co + 4);
+          v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w;
+          v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
+        }
+        if (p.shift) {
+          const float4 s0 = *reinterpret_cast<const float4*>(p.shift + co);
+          const float4 s1 = *reinterpret_cast<const float4*>(p.shift + co + 4);
+          v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w;
+          v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+        }
+        if (has_res) {
+          if (p.res_dtype == MISEG_DT_F32) {
+            const float* rp = reinterpret_cast<const float*>(p.residual) + r_off;
+            const float4 r0 = *reinterpret_cast<const float4*>(rp);
+            const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
+            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+            v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+          } else {
+            const uint4 r = *reinterpret_cast<const uint4*>(
+                reinterpret_cast<const bf16_t*>(p.residual) + r_off);
+            v[0] += bf16lo_to_f32(r.x); v[1] += bf16hi_to_f32(r.x);
+            v[2] += bf16lo_to_f32(r.y); v[3] += bf16hi_to_f32(r.y);
+            v[4] += bf16lo_to_f32(r.z); v[5] += bf16hi_to_f32(r.z);
+            v[6] += bf16lo_to_f32(r.w); v[7] += bf16hi_to_f32(r.w);
+          }
+        }
+        if (p.out) {
+          float w[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w[j] = p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
+          if (p.out_dtype == MISEG_DT_F32) {
+            float* o = reinterpret_cast<float*>(p.out) + o_off;
+            *reinterpret_cast<float4*>(o) = make_float4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(w[4], w[5], w[6], w[7]);
+          } else {
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o_off) =
+                make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]),
+                           pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
+          }
+        }
+        if (p.out2) {
+          const float4 s0 = *reinterpret_cast<const float4*>(p.scale2 + co);
+          const float4 s1 = *reinterpret_cast<const float4*>(p.scale2 + co + 4);
+          const float4 t0 = *reinterpret_cast<const float4*>(p.shift2 + co);
+          const float4 t1 = *reinterpret_cast<const float4*>(p.shift2 + co + 4);
+          *reinterpret_cast<uint4*>(p.out2 + o2_off) = make_uint4(
+              pack_bf16x2(fmaxf(v[0] * s0.x + t0.x, 0.f), fmaxf(v[1] * s0.y + t0.y, 0.f)),
+              pack_bf16x2(fmaxf(v[2] * s0.z + t0.z, 0.f), fmaxf(v[3] * s0.w + t0.w, 0.f)),
+              pack_bf16x2(fmaxf(v[4] * s1.x + t1.x, 0.f), fmaxf(v[5] * s1.y + t1.y, 0.f)),
+              pack_bf16x2(fmaxf(v[6] * s1.z + t1.z, 0.f), fmaxf(v[7] * s1.w + t1.w, 0.f)));
+        }
+        continue;
+      }
+      // ---- partial channel group (Cout tail, unaligned strides, or the softmax head) ----
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (co + j < p.Cout) {
+          if (p.scale) v[j] *= p.scale[co + j];
+          if (p.shift) v[j] += p.shift[co + j];
+          if (has_res)
+            v[j] += p.res_dtype == MISEG_DT_F32
+                        ? reinterpret_cast<const float*>(p.residual)[r_off + j]
+                        : bf16_to_f32(reinterpret_cast<const bf16_t*>(p.residual)[r_off + j]);
+        }
+      }
+      if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID) {
+        // Cout <= 4: the whole channel vector of this pixel sits in this lane (co == 0).
+        const int C = p.Cout;
+        float pr[4];
+        if (p.act == MISEG_ACT_SIGMOID) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pr[j] = 1.f / (1.f + __expf(-v[j]));
+        } else {
+          float mx = -3.0e38f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < C) mx = fmaxf(mx, v[j] * p.inv_temperature);
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            pr[j] = j < C ? __expf(v[j] * p.inv_temperature - mx) : 0.f;
+            sum += pr[j];
+          }
+          const float inv = 1.f / sum;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pr[j] *= inv;
+        }
+        float* o = reinterpret_cast<float*>(p.out) + o_off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < C) o[j] = pr[j];
+        if (p.collapse_out) {
+          // in-place semantics of the reference loop: channel i is compared with the
+          // already collapsed values (0 or collapse_value) of channels j < i.
+          float cv[4];
+          const float val = (float)p.collapse_value;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            bool win = i < C;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (j == i || j >= C) continue;
+              const float other = j < i ? cv[j] : pr[j];
+              win = win && (pr[i] > other);
+            }
+            cv[i] = win ? val : 0.f;
+          }
+          uint8_t* c8 = p.collapse_out + ((long long)n * HoWo + rem) * C;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < C) c8[j] = (uint8_t)cv[j];
+        }
+        continue;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (co + j >= p.Cout) continue;
+        if (p.out) {
+          const float w = p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
+          if (p.out_dtype == MISEG_DT_F32)
+            reinterpret_cast<float*>(p.out)[o_off + j] = w;
+          else
+            reinterpret_cast<bf16_t*>(p.out)[o_off + j] = f32_to_bf16(w);
+        }
+        if (p.out2)
+          p.out2[o2_off + j] = f32_to_bf16(fmaxf(v[j] * p.scale2[co + j] + p.shift2[co + j], 0.f));
+      }
+    }
+  }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT][MT]) {
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+}
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// ---------------------------------------------------------------------------------
+// Kernel A: register-staged, BK = 32.  Serves operands that need the BatchNorm+ReLU
+// prologue and layers whose Cin is not a multiple of 64.
+// ---------------------------------------------------------------------------------
 template <int WARPS_M, int WARPS_N, int MT, int NT, bool PRO>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WARPS_M * MT * 32;
@@ -67,43 +323,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int PB = (BN + 63) / 64;
   static_assert(WARPS_M * WARPS_N == 4, "4 waves per block");
   static_assert(BM % 64 == 0, "BM multiple of 64");
-
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * (BM + BN) * 64];
   constexpr int STAGE = (BM + BN) * 64;  // bytes per pipeline stage: A tile then B tile
   constexpr int BOFF = BM * 64;
+  constexpr int EPI = 4 * 32 * (NT * 32 + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[cmax(2 * STAGE, EPI)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WARPS_N;
   const int wn = wave % WARPS_N;
-
-  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each of
-  // the 8 groups a contiguous run of tiles, N-tiles of one M-tile adjacent.
-  const int ntot = p.mtiles * p.ntiles;
-  int tile;
-  {
-    const int bid = blockIdx.x;
-    const int q = ntot >> 3, r = ntot & 7;
-    const int x = bid & 7, loc = bid >> 3;
-    tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-  }
-  const int mtile = tile / p.ntiles;
-  const int ntile = tile - mtile * p.ntiles;
-  const int m0 = mtile * BM;
-  const int cout0 = ntile * BN;
-
-  int pad_y = p.pad_y, pad_x = p.pad_x;
-  int ph_a = 0, ph_b = 0;
-  const bf16_t* wbase = p.weight;
-  if (p.transposed) {
-    const int phase = blockIdx.y;
-    ph_a = phase >> 1;
-    ph_b = phase & 1;
-    pad_y = 1 - ph_a;
-    pad_x = 1 - ph_b;
-    wbase += (long long)phase * p.Cout * 4 * p.Cin;
-  }
+  const TileCoord tc = tile_coord<BM, BN>(p);
 
   const int KK = p.KH * p.KW;
   const int nchunk = p.Cin >> 5;
@@ -119,15 +349,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   bool a_ok[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int m = m0 + i * 64 + srow;
+    const int m = tc.m0 + i * 64 + srow;
     a_ok[i] = m < p.M;
     const int mm = a_ok[i] ? m : 0;
     const int n = mm / HoWo;
     const int rem = mm - n * HoWo;
     const int oy = rem / p.Wo;
     const int ox = rem - oy * p.Wo;
-    a_iy0[i] = oy * p.stride_y - pad_y;
-    a_ix0[i] = ox * p.stride_x - pad_x;
+    a_iy0[i] = oy * p.stride_y - tc.pad_y;
+    a_ix0[i] = ox * p.stride_x - tc.pad_x;
     a_ptr[i] = p.in + n * p.in_img_stride + (long long)a_iy0[i] * p.in_row_stride +
                (long long)a_ix0[i] * p.in_pix_stride + chunk * 8;
   }
@@ -135,9 +365,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   bool w_ok[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    const int co = cout0 + i * 64 + srow;
+    const int co = tc.cout0 + i * 64 + srow;
     w_ok[i] = (BN >= 64 || srow < BN) && co < p.Cout;
-    w_ptr[i] = wbase + (long long)(w_ok[i] ? co : 0) * KK * p.Cin + chunk * 8;
+    w_ptr[i] = tc.wbase + (long long)(w_ok[i] ? co : 0) * KK * p.Cin + chunk * 8;
   }
 
   uint4 ra[PA], rb[PB];
@@ -179,7 +409,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       if (w_ok[i]) v = *reinterpret_cast<const uint4*>(w_ptr[i] + ks * 32);
       rb[i] = v;
     }
-    // advance cursor
     if (++cc == nchunk) {
       cc = 0;
       if (++dx == p.KW) {
@@ -191,25 +420,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
   auto store_tiles = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int row = i * 64 + srow;
-      *reinterpret_cast<uint4*>(lds + buf * STAGE + swz(row, chunk)) = ra[i];
-    }
+    for (int i = 0; i < PA; ++i)
+      *reinterpret_cast<uint4*>(lds + buf * STAGE + swz64(i * 64 + srow, chunk)) = ra[i];
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int row = i * 64 + srow;
-      if (BN >= 64 || srow < BN) *reinterpret_cast<uint4*>(lds + buf * STAGE + BOFF + swz(row, chunk)) = rb[i];
-    }
+    for (int i = 0; i < PB; ++i)
+      if (BN >= 64 || srow < BN)
+        *reinterpret_cast<uint4*>(lds + buf * STAGE + BOFF + swz64(i * 64 + srow, chunk)) = rb[i];
   };
 
   f32x16 acc[NT][MT];
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int b = 0; b < MT; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
+  zero_acc<MT, NT>(acc);
   const int lrow = lane & 31;
   const int lhalf = lane >> 5;
 
@@ -219,15 +439,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const int ch = kk * 2 + lhalf;
       bf16x8 xf[MT], wf[NT];
 #pragma unroll
-      for (int b = 0; b < MT; ++b) {
-        const int row = wm * (MT * 32) + b * 32 + lrow;
-        xf[b] = *reinterpret_cast<const bf16x8*>(lds + buf * STAGE + swz(row, ch));
-      }
+      for (int b = 0; b < MT; ++b)
+        xf[b] = *reinterpret_cast<const bf16x8*>(
+            lds + buf * STAGE + swz64(wm * (MT * 32) + b * 32 + lrow, ch));
 #pragma unroll
-      for (int a = 0; a < NT; ++a) {
-        const int row = wn * (NT * 32) + a * 32 + lrow;
-        wf[a] = *reinterpret_cast<const bf16x8*>(lds + buf * STAGE + BOFF + swz(row, ch));
-      }
+      for (int a = 0; a < NT; ++a)
+        wf[a] = *reinterpret_cast<const bf16x8*>(
+            lds + buf * STAGE + BOFF + swz64(wn * (NT * 32) + a * 32 + lrow, ch));
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -236,7 +454,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
   };
 
-  // ---- main loop ----
   load_tiles(0);
   store_tiles(0);
   __syncthreads();
@@ -247,168 +464,141 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     if (ks + 1 < ksteps) store_tiles(buf ^ 1);
     __syncthreads();
   }
+  conv_epilogue<WARPS_N, MT, NT>(p, tc, acc, lds, wm, wn, lane);
+}
 
-  // ---- epilogue: each lane owns runs of 4 consecutive couts of one pixel ----
-  const bool has_res = p.residual != nullptr;
+// ---------------------------------------------------------------------------------
+// Kernel B: LDS-DMA staged (global_load_lds, 16 B per lane), BK = 64, for plain bf16
+// operands with Cin % 64 == 0.  Each wave-instruction fills 8 rows of 128 B; the LDS
+// image is lane-linear, so the chunk swizzle is applied to the per-lane SOURCE address.
+// Taps outside the image read a line of zeros instead.  Tile k+1 is in flight while the
+// MFMAs of tile k run; one vmcnt(0) + barrier per K-step.
+// ---------------------------------------------------------------------------------
+template <int WARPS_M, int WARPS_N, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p) {
+  constexpr int BM = WARPS_M * MT * 32;
+  constexpr int BN = WARPS_N * NT * 32;
+  constexpr int NA = BM / 32;  // A wave-instructions per wave per stage
+  constexpr int NB = BN / 32;
+  static_assert(WARPS_M * WARPS_N == 4, "4 waves per block");
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int BOFF = BM * 128;
+  constexpr int EPI = 4 * 32 * (NT * 32 + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[cmax(2 * STAGE, EPI)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WARPS_N;
+  const int wn = wave % WARPS_N;
+  const TileCoord tc = tile_coord<BM, BN>(p);
+
+  const int KK = p.KH * p.KW;
+  const int nchunk = p.Cin >> 6;
+  const int ksteps = KK * nchunk;
+  const int HoWo = p.Ho * p.Wo;
+
+  // lane -> (row within the 8-row group, 16-byte slot); instruction j of this wave fills
+  // rows [(4j + wave)*8, +8) of the A (or B) tile.
+  const int r8 = lane >> 3;
+  const int slot = lane & 7;
+
+  const bf16_t* a_ptr[NA];
+  int a_iy0[NA], a_ix0[NA];
+  bool a_ok[NA];
 #pragma unroll
-  for (int b = 0; b < MT; ++b) {
-    const int m = m0 + wm * (MT * 32) + b * 32 + lrow;
-    if (m >= p.M) continue;
-    const int n = m / HoWo;
-    const int rem = m - n * HoWo;
-    int oy = rem / p.Wo;
-    int ox = rem - oy * p.Wo;
-    if (p.transposed) {
-      oy = 2 * oy + ph_a;
-      ox = 2 * ox + ph_b;
+  for (int j = 0; j < NA; ++j) {
+    const int row = (4 * j + wave) * 8 + r8;
+    const int m = tc.m0 + row;
+    a_ok[j] = m < p.M;
+    const int mm = a_ok[j] ? m : 0;
+    const int n = mm / HoWo;
+    const int rem = mm - n * HoWo;
+    const int oy = rem / p.Wo;
+    const int ox = rem - oy * p.Wo;
+    a_iy0[j] = oy * p.stride_y - tc.pad_y;
+    a_ix0[j] = ox * p.stride_x - tc.pad_x;
+    const int ch = slot ^ ((row >> 1) & 7);
+    a_ptr[j] = p.in + n * p.in_img_stride + (long long)a_iy0[j] * p.in_row_stride +
+               (long long)a_ix0[j] * p.in_pix_stride + ch * 8;
+  }
+  const bf16_t* w_ptr[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int row = (4 * j + wave) * 8 + r8;
+    const int co = tc.cout0 + row;
+    const int ch = slot ^ ((row >> 1) & 7);
+    w_ptr[j] = co < p.Cout ? tc.wbase + (long long)co * KK * p.Cin + ch * 8 : nullptr;
+  }
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line) + slot * 8;
+
+  int dy = 0, dx = 0, cc = 0;
+  auto issue = [&](int ks, int buf) {
+    const int aoff = dy * p.in_row_stride + dx * p.in_pix_stride + cc * 64;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const bool ok = a_ok[j] && (unsigned)(a_iy0[j] + dy) < (unsigned)p.H &&
+                      (unsigned)(a_ix0[j] + dx) < (unsigned)p.W;
+      const bf16_t* src = ok ? a_ptr[j] + aoff : zero_src;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(lds + buf * STAGE + (4 * j + wave) * 1024),
+          16, 0, 0);
     }
-    const long long o_off = n * p.out_img_stride + (long long)oy * p.out_row_stride +
-                            (long long)ox * p.out_pix_stride;
-    const long long o2_off = n * p.out2_img_stride + (long long)oy * p.out2_row_stride +
-                             (long long)ox * p.out2_pix_stride;
-    const long long r_off = n * p.res_img_stride + (long long)oy * p.res_row_stride +
-                            (long long)ox * p.res_pix_stride;
 #pragma unroll
-    for (int a = 0; a < NT; ++a) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = cout0 + wn * (NT * 32) + a * 32 + 8 * g + 4 * lhalf;
-        if (co >= p.Cout) continue;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[a][b][4 * g + j];
-        const bool full = co + 4 <= p.Cout;
-        if (full) {
-          if (p.scale) {
-            const float4 s = *reinterpret_cast<const float4*>(p.scale + co);
-            v[0] *= s.x; v[1] *= s.y; v[2] *= s.z; v[3] *= s.w;
-          }
-          if (p.shift) {
-            const float4 s = *reinterpret_cast<const float4*>(p.shift + co);
-            v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
-          }
-          if (has_res) {
-            if (p.res_dtype == MISEG_DT_F32) {
-              const float4 r = *reinterpret_cast<const float4*>(
-                  reinterpret_cast<const float*>(p.residual) + r_off + co);
-              v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-            } else {
-              const uint2 r = *reinterpret_cast<const uint2*>(
-                  reinterpret_cast<const bf16_t*>(p.residual) + r_off + co);
-              v[0] += bf16lo_to_f32(r.x); v[1] += bf16hi_to_f32(r.x);
-              v[2] += bf16lo_to_f32(r.y); v[3] += bf16hi_to_f32(r.y);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (co + j < p.Cout) {
-              if (p.scale) v[j] *= p.scale[co + j];
-              if (p.shift) v[j] += p.shift[co + j];
-              if (has_res) {
-                v[j] += p.res_dtype == MISEG_DT_F32
-                            ? reinterpret_cast<const float*>(p.residual)[r_off + co + j]
-                            : bf16_to_f32(reinterpret_cast<const bf16_t*>(p.residual)[r_off + co + j]);
-              }
-            }
-          }
-        }
-        if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID) {
-          // Cout <= 4: the whole channel vector of this pixel sits in this lane.
-          const int C = p.Cout;
-          float pr[4];
-          if (p.act == MISEG_ACT_SIGMOID) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pr[j] = 1.f / (1.f + __expf(-v[j]));
-          } else {
-            float mx = -3.0e38f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < C) mx = fmaxf(mx, v[j] * p.inv_temperature);
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              pr[j] = j < C ? __expf(v[j] * p.inv_temperature - mx) : 0.f;
-              sum += pr[j];
-            }
-            const float inv = 1.f / sum;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pr[j] *= inv;
-          }
-          float* o = reinterpret_cast<float*>(p.out) + o_off;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < C) o[j] = pr[j];
-          if (p.collapse_out) {
-            // in-place semantics of the reference loop: channel i is compared with the
-            // already collapsed values (0 or collapse_value) of channels j < i.
-            float cv[4];
-            const float val = (float)p.collapse_value;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              bool win = i < C;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                if (j == i || j >= C) continue;
-                const float other = j < i ? cv[j] : pr[j];
-                win = win && (pr[i] > other);
-              }
-              cv[i] = win ? val : 0.f;
-            }
-            uint8_t* c8 = p.collapse_out + ((long long)n * HoWo + rem) * C;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (j < C) c8[j] = (uint8_t)cv[j];
-          }
-          continue;
-        }
-        if (p.out) {
-          float w[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) w[j] = p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
-          if (p.out_dtype == MISEG_DT_F32) {
-            float* o = reinterpret_cast<float*>(p.out) + o_off + co;
-            if (full) {
-              *reinterpret_cast<float4*>(o) = make_float4(w[0], w[1], w[2], w[3]);
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (co + j < p.Cout) o[j] = w[j];
-            }
-          } else {
-            bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + o_off + co;
-            if (full) {
-              *reinterpret_cast<uint2*>(o) =
-                  make_uint2(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]));
-            } else {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                if (co + j < p.Cout) o[j] = f32_to_bf16(w[j]);
-            }
-          }
-        }
-        if (p.out2) {
-          float w[4];
-          if (full) {
-            const float4 s = *reinterpret_cast<const float4*>(p.scale2 + co);
-            const float4 t = *reinterpret_cast<const float4*>(p.shift2 + co);
-            w[0] = fmaxf(v[0] * s.x + t.x, 0.f);
-            w[1] = fmaxf(v[1] * s.y + t.y, 0.f);
-            w[2] = fmaxf(v[2] * s.z + t.z, 0.f);
-            w[3] = fmaxf(v[3] * s.w + t.w, 0.f);
-            *reinterpret_cast<uint2*>(p.out2 + o2_off + co) =
-                make_uint2(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]));
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (co + j < p.Cout)
-                p.out2[o2_off + co + j] =
-                    f32_to_bf16(fmaxf(v[j] * p.scale2[co + j] + p.shift2[co + j], 0.f));
-          }
-        }
+    for (int j = 0; j < NB; ++j) {
+      const bf16_t* src = w_ptr[j] ? w_ptr[j] + ks * 64 : zero_src;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(lds + buf * STAGE + BOFF +
+                                                    (4 * j + wave) * 1024),
+          16, 0, 0);
+    }
+    if (++cc == nchunk) {
+      cc = 0;
+      if (++dx == p.KW) {
+        dx = 0;
+        ++dy;
       }
     }
+  };
+
+  f32x16 acc[NT][MT];
+  zero_acc<MT, NT>(acc);
+  const int lrow = lane & 31;
+  const int lhalf = lane >> 5;
+
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ch = kk * 2 + lhalf;
+      bf16x8 xf[MT], wf[NT];
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+        xf[b] = *reinterpret_cast<const bf16x8*>(
+            lds + buf * STAGE + swz128(wm * (MT * 32) + b * 32 + lrow, ch));
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+        wf[a] = *reinterpret_cast<const bf16x8*>(
+            lds + buf * STAGE + BOFF + swz128(wn * (NT * 32) + a * 32 + lrow, ch));
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  issue(0, 0);
+  for (int ks = 0; ks < ksteps; ++ks) {
+    // tile ks has landed (own DMA retired, then everyone's after the barrier); the barrier
+    // also means every wave is done reading the other buffer, which tile ks+1 now overwrites
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ks + 1 < ksteps) issue(ks + 1, (ks + 1) & 1);
+    compute(ks & 1);
   }
+  conv_epilogue<WARPS_N, MT, NT>(p, tc, acc, lds, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------
@@ -428,9 +618,11 @@ static const TileCfg kCfgs[] = {
 };
 
 template <int WM, int WN, int MT, int NT>
-static hipError_t launch_cfg(const ConvParams& p, dim3 grid, bool pro, hipStream_t s) {
+static hipError_t launch_cfg(const ConvParams& p, dim3 grid, bool pro, bool dma, hipStream_t s) {
   if (pro)
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, true>), grid, dim3(256), 0, s, p);
+  else if (dma)
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, MT, NT>), grid, dim3(256), 0, s, p);
   else
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, false>), grid, dim3(256), 0, s, p);
   return hipGetLastError();
@@ -524,7 +716,7 @@ int validate_conv(const miseg_conv_desc* d) {
     set_error("conv: N*Ho*Wo=%lld exceeds 2^31", M);
     return MISEG_E_UNSUPPORTED_SHAPE;
   }
-  MISEG_CHECK_ARG(d->tile_hint >= 0 && d->tile_hint <= (int)(sizeof(kCfgs) / sizeof(kCfgs[0])),
+  MISEG_CHECK_ARG(d->tile_hint >= 0 && (d->tile_hint & 15) <= (int)(sizeof(kCfgs) / sizeof(kCfgs[0])),
                   "conv: bad tile_hint");
   return MISEG_OK;
 }
@@ -563,21 +755,37 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   p.inv_temperature = d->act == MISEG_ACT_SOFTMAX ? 1.f / d->temperature : 1.f;
   p.collapse_value = d->collapse_value;
   p.M = d->N * d->Ho * d->Wo;
-  const int cfg = d->tile_hint ? d->tile_hint : choose_cfg(p.M, d->Cout);
+  const int hint = d->tile_hint & 15;
+  const int cfg = hint ? hint : choose_cfg(p.M, d->Cout);
   const TileCfg tc = kCfgs[cfg - 1];
   p.mtiles = (p.M + tc.bm - 1) / tc.bm;
   p.ntiles = (d->Cout + tc.bn - 1) / tc.bn;
   const dim3 grid(p.mtiles * p.ntiles, d->transposed ? 4 : 1, 1);
   const bool pro = d->in_scale != nullptr;
+  const bool dma = !pro && (d->Cin & 63) == 0 && !(d->tile_hint & MISEG_TILE_NO_DMA);
+  auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
+    return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
+  };
+  p.vec_ok = 1;
+  if (d->out)
+    p.vec_ok &= al(d->out, d->out_pix_stride, d->out_row_stride, d->out_img_stride,
+                   d->out_dtype == MISEG_DT_F32 ? 3 : 7);
+  if (d->out2)
+    p.vec_ok &= al(d->out2, d->out2_pix_stride, d->out2_row_stride, d->out2_img_stride, 7);
+  if (d->residual)
+    p.vec_ok &= al(d->residual, d->res_pix_stride, d->res_row_stride, d->res_img_stride,
+                   d->res_dtype == MISEG_DT_F32 ? 3 : 7);
+  if (d->scale2) p.vec_ok &= ((uintptr_t)d->scale2 & 15) == 0 && ((uintptr_t)d->shift2 & 15) == 0;
+  if (d->act == MISEG_ACT_SOFTMAX || d->act == MISEG_ACT_SIGMOID) p.vec_ok = 0;
   hipError_t e;
   switch (cfg) {
-    case 1: e = launch_cfg<2, 2, 2, 2>(p, grid, pro, stream); break;
-    case 2: e = launch_cfg<4, 1, 2, 2>(p, grid, pro, stream); break;
-    case 3: e = launch_cfg<4, 1, 2, 1>(p, grid, pro, stream); break;
-    case 4: e = launch_cfg<2, 2, 1, 1>(p, grid, pro, stream); break;
-    case 5: e = launch_cfg<4, 1, 1, 2>(p, grid, pro, stream); break;
-    case 6: e = launch_cfg<4, 1, 1, 1>(p, grid, pro, stream); break;
-    default: e = launch_cfg<2, 2, 1, 2>(p, grid, pro, stream); break;
+    case 1: e = launch_cfg<2, 2, 2, 2>(p, grid, pro, dma, stream); break;
+    case 2: e = launch_cfg<4, 1, 2, 2>(p, grid, pro, dma, stream); break;
+    case 3: e = launch_cfg<4, 1, 2, 1>(p, grid, pro, dma, stream); break;
+    case 4: e = launch_cfg<2, 2, 1, 1>(p, grid, pro, dma, stream); break;
+    case 5: e = launch_cfg<4, 1, 1, 2>(p, grid, pro, dma, stream); break;
+    case 6: e = launch_cfg<4, 1, 1, 1>(p, grid, pro, dma, stream); break;
+    default: e = launch_cfg<2, 2, 1, 2>(p, grid, pro, dma, stream); break;
   }
   if (e != hipSuccess) {
     set_error("conv launch failed: %s", hipGetErrorString(e));

@@ -1,0 +1,279 @@
+"""Keras-like `Model` object over the HIP engine: the surface the reference's
+callers use on what `make_model` / `load_model` return
+(/root/reference utils/model.py:118,135-141,228-234,272-276;
+utils/predict.py:70,159; utils/evaluate.py:127; model_train.py:281-329).
+"""
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import losses as LS
+from . import netspec
+from . import weights as W
+
+CONTAINER_VERSION = 1
+
+
+class Adam:
+    """Hyper-parameter holder with the Keras 2.10 defaults (epsilon 1e-7)."""
+
+    def __init__(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self.learning_rate = float(learning_rate)
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+
+    def get_config(self):
+        return {"name": "Adam", "learning_rate": self.learning_rate, "beta_1": self.beta_1,
+                "beta_2": self.beta_2, "epsilon": self.epsilon}
+
+
+class DeviceArray:
+    """Result of a forward pass: a device tensor that indexes like an eager
+    tensor and converts with `.numpy()` (utils/predict.py:159 does
+    `model(batch, training=False)[0].numpy()`)."""
+
+    def __init__(self, t):
+        self.tensor = t
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def __getitem__(self, idx):
+        return DeviceArray(self.tensor[idx])
+
+    def numpy(self):
+        return self.tensor.detach().cpu().numpy()
+
+    def __array__(self, dtype=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+
+class LayerView:
+    def __init__(self, model, layer):
+        self._m, self._l = model, layer
+        self.name = layer.name
+
+    @property
+    def output(self):
+        return self._l.out
+
+    @property
+    def output_shape(self):
+        return self._l.output_shape
+
+    def get_config(self):
+        return dict(self._l.config, name=self._l.name)
+
+    def get_weights(self):
+        return [self._m.weights[self.name][w] for w, _, _ in self._l.weights]
+
+    def set_weights(self, arrays):
+        for (w, shape, _), a in zip(self._l.weights, arrays):
+            a = np.asarray(a, np.float32)
+            if tuple(a.shape) != tuple(shape):
+                raise ValueError("layer %s weight %s: expected %r, got %r" % (self.name, w, shape, a.shape))
+            self._m.weights[self.name][w] = a
+        self._m._invalidate()
+
+    def count_params(self):
+        return self._l.count_params()
+
+
+class Model:
+    def __init__(self, graph, weights=None, seed=None, device="cuda:0"):
+        self.graph = graph
+        self.weights = weights if weights is not None else W.init_weights(graph, seed=seed)
+        self._name = graph.name
+        self.device = device
+        self.optimizer = None
+        self.loss = None
+        self.metrics = []
+        self.encoder_freeze = False
+        self._engines = {}
+
+    # ---- identity -----------------------------------------------------------
+    @property
+    def name(self):
+        return self._name
+
+    @property
+    def input_shape(self):
+        h, w, c = self.graph.input_shape
+        return (None, h, w, c)
+
+    @property
+    def output_shape(self):
+        h, w, _ = self.graph.input_shape
+        return (None, h, w, self.graph.classes)
+
+    @property
+    def layers(self):
+        return [LayerView(self, l) for l in self.graph.layers.values()]
+
+    def get_layer(self, name=None, index=None):
+        if name is not None:
+            return LayerView(self, self.graph.layers[name])
+        return self.layers[index]
+
+    def count_params(self):
+        return self.graph.count_params()
+
+    def summary(self, print_fn=print):
+        print_fn('Model: "%s"' % self.name)
+        print_fn("%-44s %-26s %12s" % ("Layer (type)", "Output Shape", "Param #"))
+        print_fn("=" * 84)
+        for l in self.graph.layers.values():
+            print_fn("%-44s %-26s %12d" % ("%s (%s)" % (l.name, l.cls), str(l.output_shape),
+                                           l.count_params()))
+        total = self.count_params()
+        non_trainable = sum(int(np.prod(s)) for _, w, s, _ in self.graph.weight_spec()
+                            if w in ("moving_mean", "moving_variance"))
+        print_fn("=" * 84)
+        print_fn("Total params: %d" % total)
+        print_fn("Trainable params: %d" % (total - non_trainable))
+        print_fn("Non-trainable params: %d" % non_trainable)
+
+    # ---- weights / config -----------------------------------------------------
+    def _invalidate(self):
+        self._engines = {}
+
+    def get_weights(self):
+        return W.to_list(self.graph, self.weights)
+
+    def set_weights(self, arrays):
+        self.weights = W.from_list(self.graph, arrays)
+        self._invalidate()
+
+    def get_config(self):
+        g = self.graph
+        layers = [{"name": l.name, "class_name": l.cls, "config": dict(l.config, name=l.name),
+                   "inbound_nodes": [[[n, 0, 0, {}] for n in l.inbound]] if l.inbound else []}
+                  for l in g.layers.values()]
+        return {"name": self.name, "layers": layers,
+                "input_layers": [[layers[0]["name"], 0, 0]],
+                "output_layers": [[layers[-1]["name"], 0, 0]],
+                "miseg": {"encoder": g.encoder, "decoder": g.decoder, "classes": g.classes,
+                          "activation": g.activation, "temperature": g.temperature}}
+
+    def to_json(self):
+        return json.dumps({"class_name": "Functional", "config": self.get_config(),
+                           "backend": "miseg_amd", "keras_version": "2.10.0"})
+
+    def compile(self, optimizer=None, loss=None, metrics=None):
+        self.optimizer = optimizer if optimizer is not None else Adam()
+        self.loss = loss
+        flat = []
+        for m in (metrics or []):
+            flat.extend(m if isinstance(m, (list, tuple)) else [m])
+        self.metrics = flat
+
+    # ---- execution -----------------------------------------------------------------
+    def _engine(self, batch):
+        from . import engine
+        e = self._engines.get(batch)
+        if e is None:
+            self._engines = {}          # one resident plan at a time: buffers are per batch size
+            e = engine.Engine(self.graph, self.weights, batch=batch, device=self.device)
+            self._engines[batch] = e
+        return e
+
+    def __call__(self, batch, training=False):
+        if training:
+            raise NotImplementedError("training-mode forward (batch statistics) is not built yet")
+        if isinstance(batch, DeviceArray):
+            batch = batch.tensor
+        n = batch.shape[0]
+        eng = self._engine(n)
+        probs = eng.forward(batch)
+        return DeviceArray(probs.clone())
+
+    def predict(self, x, batch_size=1, verbose=0):
+        out = []
+        for i in range(0, len(x), batch_size):
+            out.append(self(x[i:i + batch_size], training=False).numpy())
+        return np.concatenate(out, axis=0)
+
+    def predict_masks(self, batch, pixel_intensity=127):
+        """Forward + collapse_probabilities (utils/utils.py:50-68) on the device:
+        returns uint8 (n,H,W,classes)."""
+        n = batch.shape[0]
+        eng = self._engine(n)
+        if pixel_intensity != eng.collapse_value:
+            raise ValueError("the plan was built for pixel_intensity=%d" % eng.collapse_value)
+        eng.forward(batch)
+        return eng.mask[:n].cpu().numpy()
+
+    def evaluate(self, dataset, return_dict=True, verbose=0, steps=None):
+        """Mean over batches of loss and metrics, as Keras logs them.  `dataset`
+        yields (images, one-hot masks)."""
+        loss = self.loss or LS.cce_dice_loss
+        if isinstance(loss, str):
+            loss = {"categorical_crossentropy": LS.categorical_crossentropy}.get(loss, LS.cce_dice_loss)
+        names = ["loss"] + [getattr(m, "name", getattr(m, "__name__", str(m))) for m in self.metrics]
+        totals = np.zeros(len(names))
+        count = 0
+        for images, masks in dataset:
+            pr = self(np.asarray(images, np.float32) if not isinstance(images, torch.Tensor) else images)
+            s, pixels = LS.class_sums(masks, pr.tensor)
+            vals = [loss.from_sums(s, pixels)] + [m.from_sums(s, pixels) for m in self.metrics]
+            totals += np.asarray(vals)
+            count += 1
+            if steps is not None and count >= steps:
+                break
+        if count == 0:
+            raise ValueError("evaluate() got an empty dataset")
+        means = totals / count
+        return dict(zip(names, map(float, means))) if return_dict else list(map(float, means))
+
+    def fit(self, *args, **kwargs):
+        raise NotImplementedError(
+            "Model.fit is not built yet: the backward kernels (conv dgrad/wgrad, BatchNorm "
+            "batch statistics, loss gradient, Adam) are the next milestone of this package")
+
+    # ---- persistence -----------------------------------------------------------------
+    def save(self, path):
+        """Single-file container (numpy .npz): the JSON config plus every weight
+        under '<layer>/<weight>:0', the key an .h5 written by Keras uses inside
+        'model_weights'.  Written atomically."""
+        arrays = {"__config__": np.frombuffer(self.to_json().encode(), dtype=np.uint8),
+                  "__version__": np.asarray([CONTAINER_VERSION])}
+        for l, w, _, _ in self.graph.weight_spec():
+            arrays["%s/%s:0" % (l, w)] = self.weights[l][w]
+        tmp = str(path) + ".tmp"
+        with open(tmp, "wb") as f:
+            np.savez(f, **arrays)
+        os.replace(tmp, str(path))
+
+
+def model_from_json(text, custom_objects=None):
+    cfg = json.loads(text)["config"]
+    meta = cfg.get("miseg")
+    if meta is None:
+        raise ValueError("this JSON was not written by miseg_amd.Model.to_json(): no 'miseg' block")
+    shape = cfg["layers"][0]["config"]["batch_input_shape"][1:]
+    g = netspec.build_graph(meta["encoder"], meta["decoder"], tuple(shape), meta["classes"],
+                            activation=meta["activation"], temperature=meta["temperature"],
+                            name=cfg.get("name"))
+    return Model(g, seed=0)
+
+
+def load_container(path):
+    with np.load(str(path), allow_pickle=False) as z:
+        text = bytes(z["__config__"]).decode()
+        model = model_from_json(text)
+        weights = OrderedDict()
+        for l, w, shape, _ in model.graph.weight_spec():
+            a = z["%s/%s:0" % (l, w)]
+            if tuple(a.shape) != tuple(shape):
+                raise ValueError("%s/%s: stored shape %r does not match the graph's %r" % (l, w, a.shape, shape))
+            weights.setdefault(l, OrderedDict())[w] = a.astype(np.float32)
+    model.weights = weights
+    return model

@@ -1,0 +1,58 @@
+"""The N>1 path on CPU: two gloo ranks shard a list of images round-robin, every
+image is processed exactly once, and the whole-job figures (max elapsed time,
+summed image count) are what bench.py reports."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_items, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import miseg_amd
+    from miseg_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard.shard_indices(n_items, rank, world)
+    shard.barrier()
+    elapsed = shard.max_over_ranks(1.0 + rank)
+    total = shard.sum_over_ranks(len(mine))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 0:
+        torch.save({"elapsed": elapsed, "total": total, "gathered": gathered}, os.path.join(out_dir, "r.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [7, 8, 1])
+def test_two_rank_sharding(tmp_path, n_items):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_items, str(tmp_path)), nprocs=world, join=True)
+    r = torch.load(os.path.join(str(tmp_path), "r.pt"))
+    assert r["elapsed"] == 2.0                    # the slower rank
+    assert r["total"] == n_items
+    flat = sorted(i for part in r["gathered"] for i in part)
+    assert flat == list(range(n_items))           # every image exactly once
+    assert abs(len(r["gathered"][0]) - len(r["gathered"][1])) <= 1
+
+
+def test_tile_ranges_match_reference_patch_predict():
+    import miseg_amd
+    from miseg_amd import shard
+    assert shard.tile_ranges(1920, 512) == [(0, 512), (512, 1024), (1024, 1536), (1408, 1920)]
+    assert shard.tile_ranges(2560, 2560) == [(0, 2560)]
+    with pytest.raises(ValueError):
+        shard.shard_indices(4, 2, 2)

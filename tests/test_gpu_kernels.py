@@ -117,8 +117,10 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23])
 def test_conv_plain(env, case, hint):
+    """hint & 15 picks the tile shape; hint & 16 forces the register-staged path where the
+    LDS-DMA path (Cin % 64 == 0) would be chosen."""
     n, h, w, cin, cout, k, stride, pad = case
     rng = np.random.default_rng(hash(case) % 2**32)
     x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
