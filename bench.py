@@ -140,16 +140,29 @@ def main():
                 op_ms[i] += eng.time_ops(i, i + 1)
         op_ms /= reps
         macs = np.array([eng.op_macs(i) for i in range(nops)], dtype=np.float64)
+        kernels = [eng.op_kernel(i) for i in range(nops)]
         is_conv = macs > 0
         conv_ms = op_ms[is_conv].sum()
         conv_flops = 2.0 * macs.sum()
-        dom = int(np.argmax(op_ms))
-        dom_tflops = 2.0 * macs[dom] / (op_ms[dom] * 1e-3) / 1e12
+        # group launches by device kernel (template instantiation), as rocprofv3 --stats does
+        groups = {}
+        for i in range(nops):
+            g = groups.setdefault(kernels[i], {"launches": 0, "ms": 0.0, "flops": 0.0})
+            g["launches"] += 1
+            g["ms"] += op_ms[i]
+            g["flops"] += 2.0 * macs[i]
+        dom_name = max(groups, key=lambda k: groups[k]["ms"])
+        dom = groups[dom_name]
+        dom_tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         if args.per_op:
             for i in range(nops):
                 tf = 2.0 * macs[i] / (op_ms[i] * 1e-3) / 1e12 if macs[i] else 0.0
-                print("%3d %-32s %8.3f ms %8.2f GMAC %8.1f TFLOP/s" %
-                      (i, eng.op_names[i], op_ms[i], macs[i] / 1e9, tf), file=sys.stderr)
+                print("%3d %-32s %-36s %8.3f ms %8.2f GMAC %8.1f TFLOP/s" %
+                      (i, eng.op_names[i], kernels[i], op_ms[i], macs[i] / 1e9, tf), file=sys.stderr)
+            for k, g in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
+                print("%-40s launches %3d  total %8.3f ms  avg %8.4f ms  %8.1f TFLOP/s" %
+                      (k, g["launches"], g["ms"], g["ms"] / g["launches"],
+                       g["flops"] / (g["ms"] * 1e-3) / 1e12), file=sys.stderr)
             print("sum of per-op times %.3f ms (conv %.3f ms)" % (op_ms.sum(), conv_ms), file=sys.stderr)
         images = args.batch * world * args.steps
         result = {
@@ -172,13 +185,15 @@ def main():
                        "parallelism": "independent images per GPU, no collective"},
             "roofline": {
                 "bound": "mfma",
-                "kernel": "conv_igemm_kernel launch '%s'" % eng.op_names[dom],
+                "kernel": dom_name,
+                "launches_per_step": dom["launches"],
+                "avg_launch_ms": dom["ms"] / dom["launches"],
+                "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
                 "achieved": dom_tflops,
                 "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": None,
-                "launch_ms": op_ms[dom],
                 "all_conv_launches": {
                     "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
                     "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,

@@ -207,6 +207,8 @@ int miseg_plan_run(const miseg_plan* p, void* stream);
 int miseg_plan_run_range(const miseg_plan* p, int first, int last, void* stream, float* ms);
 /* Algorithmic multiply-accumulates of conv op `index` (0 for other ops). */
 int64_t miseg_plan_op_macs(const miseg_plan* p, int index);
+/* Name of the device kernel op `index` launches (as a profiler prints it), into buf. */
+int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t buflen);
 
 #ifdef __cplusplus
 }

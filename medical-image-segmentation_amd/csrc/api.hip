@@ -19,6 +19,7 @@ void set_error(const char* fmt, ...) {
 
 int launch_conv(const miseg_conv_desc* d, hipStream_t stream);
 int validate_conv(const miseg_conv_desc* d);
+void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len);
 int launch_prep_input(const float*, void*, const float*, const float*, int, int, int, hipStream_t);
 int launch_maxpool3x3s2(const void*, void*, const float*, const float*, int, int, int, int, int,
                         int, hipStream_t);
@@ -259,6 +260,20 @@ int64_t miseg_plan_op_macs(const miseg_plan* p, int index) {
   const miseg_conv_desc& d = o.conv;
   const int64_t per = (int64_t)d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin;
   return d.transposed ? 4 * per : per;
+}
+
+int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t buflen) {
+  MISEG_CHECK_ARG(p && buf && buflen > 0, "plan_op_kernel: null argument");
+  MISEG_CHECK_ARG(index >= 0 && index < (int)p->ops.size(), "plan_op_kernel: bad index");
+  const Op& o = p->ops[index];
+  static const char* names[] = {"", "prep_input_kernel", "maxpool3x3s2_kernel", "avgpool2x2_kernel",
+                                "upsample_nearest_kernel", "upsample_bilinear2x_kernel",
+                                "scale_shift_relu_kernel"};
+  if (o.kind == OP_CONV)
+    conv_kernel_name(&o.conv, buf, buflen);
+  else
+    snprintf(buf, buflen, "%s", names[o.kind]);
+  return MISEG_OK;
 }
 
 }  // extern "C"

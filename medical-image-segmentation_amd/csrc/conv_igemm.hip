@@ -721,6 +721,21 @@ int validate_conv(const miseg_conv_desc* d) {
   return MISEG_OK;
 }
 
+// Name of the kernel instantiation launch_conv() picks for `d`, as rocprofv3 prints it.
+void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
+  const int hint = d->tile_hint & 15;
+  const int M = d->N * d->Ho * d->Wo;
+  const int cfg = hint ? hint : choose_cfg(M, d->Cout);
+  static const char* shapes[] = {"2, 2, 2, 2", "4, 1, 2, 2", "4, 1, 2, 1", "2, 2, 1, 1",
+                                 "4, 1, 1, 2", "4, 1, 1, 1", "2, 2, 1, 2"};
+  const bool pro = d->in_scale != nullptr;
+  const bool dma = !pro && (d->Cin & 63) == 0 && !(d->tile_hint & MISEG_TILE_NO_DMA);
+  if (dma)
+    snprintf(buf, len, "conv_igemm_dma_kernel<%s>", shapes[cfg - 1]);
+  else
+    snprintf(buf, len, "conv_igemm_kernel<%s, %s>", shapes[cfg - 1], pro ? "true" : "false");
+}
+
 int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   int rc = validate_conv(d);
   if (rc != MISEG_OK) return rc;

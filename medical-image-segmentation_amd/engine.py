@@ -477,3 +477,8 @@ class Engine:
 
     def op_macs(self, i):
         return int(self.lib.miseg_plan_op_macs(self.plan, i))
+
+    def op_kernel(self, i):
+        buf = C.create_string_buffer(128)
+        L.check(self.lib.miseg_plan_op_kernel(self.plan, i, buf, 128))
+        return buf.value.decode()

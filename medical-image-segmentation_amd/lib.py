@@ -68,6 +68,7 @@ SIGNATURES = {
     "miseg_plan_run": (C.c_int, [_VP, _VP]),
     "miseg_plan_run_range": (C.c_int, [_VP, C.c_int, C.c_int, _VP, C.POINTER(C.c_float)]),
     "miseg_plan_op_macs": (C.c_int64, [_VP, C.c_int]),
+    "miseg_plan_op_kernel": (C.c_int, [_VP, C.c_int, C.c_char_p, _I32]),
 }
 
 _lib = None
