@@ -14,9 +14,22 @@
 // [BM pixels] x [BN couts] tile, double-buffered in LDS with one barrier per K-step.
 // Two staging paths: LDS-DMA (global_load_lds, BK = 64) for plain bf16 operands, and a
 // register-staged path (BK = 32) that can apply BatchNorm+ReLU to the operand on the way.
+#include <utility>
+
 #include "common.h"
 
 namespace miseg {
+
+// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  Keeps
+// accumulator arrays indexed by constants only (a runtime index would move them to scratch).
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -52,6 +65,7 @@ struct ConvParams {
   int mtiles;   // ceil(M / BM)
   int ntiles;   // ceil(Cout / BN)
   int vec_ok;   // strides/pointers allow 16-byte epilogue accesses
+  int tiles_y, tiles_x;  // halo kernel: output patches per image
 };
 
 // 16 zero bytes x 8: the source of LDS-DMA loads for taps that fall outside the image.
@@ -108,10 +122,24 @@ __device__ __forceinline__ TileCoord tile_coord(const ConvParams& p) {
 // 16-byte bf16 stores (32-byte fp32), residual loads of the same shape, and the
 // channels of a pixel written by adjacent lanes.
 // ---------------------------------------------------------------------------------
-template <int WARPS_N, int MT, int NT>
+// Maps a pixel index inside a linear (row-major over N*Ho*Wo) block tile to coordinates.
+struct LinearDecode {
+  int m0, M, HoWo, Wo;
+  __device__ __forceinline__ bool operator()(int idx, int& n, int& oy, int& ox, int& rem) const {
+    const int m = m0 + idx;
+    if (m >= M) return false;
+    n = m / HoWo;
+    rem = m - n * HoWo;
+    oy = rem / Wo;
+    ox = rem - oy * Wo;
+    return true;
+  }
+};
+
+template <int WARPS_N, int MT, int NT, class Decode>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoord& tc,
-                                              f32x16 (&acc)[NT][MT], unsigned char* lds, int wm,
-                                              int wn, int lane) {
+                                              const Decode& decode, f32x16 (&acc)[NT][MT],
+                                              unsigned char* lds, int wm, int wn, int lane) {
   constexpr int TNW = NT * 32;       // couts per wave tile
   constexpr int ROWF = TNW + 4;      // floats per LDS row
   constexpr int LPP = TNW / 8;       // lanes per pixel when reading back
@@ -128,8 +156,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
   const bool co_any = co < p.Cout;
   const bool full = co + 8 <= p.Cout && p.vec_ok;
 
-#pragma unroll
-  for (int b = 0; b < MT; ++b) {
+  static_for<MT>([&](auto bc) __attribute__((always_inline)) {
+    constexpr int b = decltype(bc)::value;
     __syncthreads();
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -142,12 +170,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int px = ps * PPP + px_l;
-      const int m = tc.m0 + wm * (MT * 32) + b * 32 + px;
-      if (m >= p.M || !co_any) continue;
-      const int n = m / HoWo;
-      const int rem = m - n * HoWo;
-      int oy = rem / p.Wo;
-      int ox = rem - oy * p.Wo;
+      int n, oy, ox, rem;
+      if (!co_any || !decode(wm * (MT * 32) + b * 32 + px, n, oy, ox, rem)) continue;
       if (p.transposed) {
         oy = 2 * oy + tc.ph_a;
         ox = 2 * ox + tc.ph_b;
@@ -296,7 +320,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
           p.out2[o2_off + j] = f32_to_bf16(fmaxf(v[j] * p.scale2[co + j] + p.shift2[co + j], 0.f));
       }
     }
-  }
+  });
 }
 
 template <int MT, int NT>
@@ -433,7 +457,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int lrow = lane & 31;
   const int lhalf = lane >> 5;
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ch = kk * 2 + lhalf;
@@ -464,7 +488,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     if (ks + 1 < ksteps) store_tiles(buf ^ 1);
     __syncthreads();
   }
-  conv_epilogue<WARPS_N, MT, NT>(p, tc, acc, lds, wm, wn, lane);
+  const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
+  conv_epilogue<WARPS_N, MT, NT>(p, tc, dec, acc, lds, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------
@@ -568,25 +593,31 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   const int lrow = lane & 31;
   const int lhalf = lane >> 5;
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    // fragment reads run two 16-deep sub-steps ahead of the MFMAs that consume them
+    bf16x8 xf[2][MT], wf[2][NT];
+#define MISEG_RD(KK)                                                                        \
+  {                                                                                         \
+    const int ch = (KK) * 2 + lhalf;                                                        \
+    _Pragma("unroll") for (int b = 0; b < MT; ++b) xf[(KK) & 1][b] =                        \
+        *reinterpret_cast<const bf16x8*>(lds + buf * STAGE + swz128(wm * (MT * 32) + b * 32 + lrow, ch));                                               \
+    _Pragma("unroll") for (int a = 0; a < NT; ++a) wf[(KK) & 1][a] =                        \
+        *reinterpret_cast<const bf16x8*>(lds + buf * STAGE + BOFF + swz128(wn * (NT * 32) + a * 32 + lrow, ch));                                               \
+  }
+    MISEG_RD(0)
+    MISEG_RD(1)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const int ch = kk * 2 + lhalf;
-      bf16x8 xf[MT], wf[NT];
-#pragma unroll
-      for (int b = 0; b < MT; ++b)
-        xf[b] = *reinterpret_cast<const bf16x8*>(
-            lds + buf * STAGE + swz128(wm * (MT * 32) + b * 32 + lrow, ch));
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-        wf[a] = *reinterpret_cast<const bf16x8*>(
-            lds + buf * STAGE + BOFF + swz128(wn * (NT * 32) + a * 32 + lrow, ch));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][a], xf[kk & 1][b],
+                                                              acc[a][b], 0, 0, 0);
+      if (kk + 2 < 4) MISEG_RD(kk + 2)
     }
+#undef MISEG_RD
   };
 
   issue(0, 0);
@@ -598,7 +629,207 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     if (ks + 1 < ksteps) issue(ks + 1, (ks + 1) & 1);
     compute(ks & 1);
   }
-  conv_epilogue<WARPS_N, MT, NT>(p, tc, acc, lds, wm, wn, lane);
+  const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
+  conv_epilogue<WARPS_N, MT, NT>(p, tc, dec, acc, lds, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel C: 3x3, stride 1, pad 1 with the input halo tile resident in LDS.  A block of 8
+// waves computes a TH x TW patch of output pixels for BN couts.  Per 64-channel chunk the
+// (TH+2) x (TW+2) input halo is brought into LDS once by LDS-DMA and serves all nine
+// taps (the pixel operand of tap (dy,dx) is the same image read at a shifted row), so
+// the global->LDS traffic per K-step is one [BN][64] weight tile plus 1/9 of a halo
+// instead of a [BM][64] activation tile.  Weight tiles are double buffered per tap, the
+// next chunk's halo is fetched one wave-instruction per tap step.
+// ---------------------------------------------------------------------------------
+template <int TH, int TW>
+struct PatchDecode {
+  int n, y0, x0, Ho, Wo;
+  __device__ __forceinline__ bool operator()(int idx, int& n_, int& oy, int& ox, int& rem) const {
+    oy = y0 + idx / TW;
+    ox = x0 + idx % TW;
+    if (oy >= Ho || ox >= Wo) return false;
+    n_ = n;
+    rem = oy * Wo + ox;
+    return true;
+  }
+};
+
+template <int TH, int TW, int WARPS_M, int WARPS_N, int MT, int NT, int HB>
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(const ConvParams p) {
+  // HB = 2: halo double buffered (next chunk fetched during the current one's taps);
+  // HB = 1: one halo buffer, refilled between chunks -- half the LDS, so two blocks share a
+  //         CU and cover each other's refill.
+  constexpr int NW = WARPS_M * WARPS_N;
+  static_assert(NW == 8 || NW == 4, "4 or 8 waves per block");
+  constexpr int BM = TH * TW;
+  constexpr int BN = WARPS_N * NT * 32;
+  static_assert(BM == WARPS_M * MT * 32, "pixel tile must match the wave layout");
+  constexpr int HWD = TW + 2;
+  constexpr int HROWS = (TH + 2) * HWD;          // halo pixels, one 128-B LDS row each
+  constexpr int NHI = (HROWS + 7) / 8;           // halo wave-instructions per chunk
+  constexpr int NHW = (NHI + NW - 1) / NW;       // ... per wave
+  static_assert(HB == 1 || NHW <= 9, "next halo must fit in the nine tap steps of a chunk");
+  constexpr int HALO_BYTES = NHI * 1024;
+  constexpr int NBI = BN / 8;                    // weight wave-instructions per K-step
+  constexpr int NBW = (NBI + NW - 1) / NW;
+  constexpr int W_BYTES = BN * 128;
+  constexpr int WOFF = HB * HALO_BYTES;
+  constexpr int EPI = NW * 32 * (NT * 32 + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[cmax(HB * HALO_BYTES + 2 * W_BYTES, EPI)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WARPS_N;
+  const int wn = wave % WARPS_N;
+  const TileCoord tc = tile_coord<BM, BN>(p);
+  const int mtile = tc.m0 / BM;
+  const int per_img = p.tiles_y * p.tiles_x;
+  const int n = mtile / per_img;
+  const int trem = mtile - n * per_img;
+  const int tyi = trem / p.tiles_x;
+  const int y0 = tyi * TH;
+  const int x0 = (trem - tyi * p.tiles_x) * TW;
+
+  const int nchunk = p.Cin >> 6;
+  const int steps = nchunk * 9;
+  const int r8 = lane >> 3;
+  const int slot = lane & 7;
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line) + slot * 8;
+
+  // halo sources: instruction j of this wave fills halo rows [(j*NW + wave)*8, +8)
+  const bf16_t* h_src[NHW];
+#pragma unroll
+  for (int j = 0; j < NHW; ++j) {
+    const int hr = (j * NW + wave) * 8 + r8;
+    const int hy = hr / HWD;
+    const int hx = hr - hy * HWD;
+    const int iy = y0 - 1 + hy;
+    const int ix = x0 - 1 + hx;
+    const bool ok = hr < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const int ch = slot ^ ((hr >> 1) & 7);
+    h_src[j] = ok ? p.in + n * p.in_img_stride + (long long)iy * p.in_row_stride +
+                        (long long)ix * p.in_pix_stride + ch * 8
+                  : nullptr;
+  }
+  const bf16_t* w_src[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const int row = (j * NW + wave) * 8 + r8;
+    const int co = tc.cout0 + row;
+    const int ch = slot ^ ((row >> 1) & 7);
+    w_src[j] = (row < BN && co < p.Cout) ? tc.wbase + (long long)co * 9 * p.Cin + ch * 8 : nullptr;
+  }
+
+  auto issue_halo = [&](int j, int chunk, int hb) {
+    if ((j * NW + wave) < NHI) {
+      const bf16_t* src = h_src[j] ? h_src[j] + chunk * 64 : zero_src;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(lds + hb * HALO_BYTES + (j * NW + wave) * 1024),
+          16, 0, 0);
+    }
+  };
+  auto issue_w = [&](int tap, int chunk, int wb) {
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      if ((j * NW + wave) < NBI) {
+        const bf16_t* src = w_src[j] ? w_src[j] + tap * p.Cin + chunk * 64 : zero_src;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)src,
+            (__attribute__((address_space(3))) void*)(lds + WOFF + wb * W_BYTES +
+                                                      (j * NW + wave) * 1024),
+            16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[NT][MT];
+  zero_acc<MT, NT>(acc);
+  const int lrow = lane & 31;
+  const int lhalf = lane >> 5;
+  int hr0[MT];   // halo row of this lane's pixel for tap (0,0)
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    const int pidx = (wm * MT + b) * 32 + lrow;
+    hr0[b] = (pidx / TW) * HWD + (pidx % TW);
+  }
+
+  auto compute = [&](int hb, int wb, int dy, int dx) __attribute__((always_inline)) {
+    const unsigned char* hbase = lds + hb * HALO_BYTES;
+    const unsigned char* wbase = lds + WOFF + wb * W_BYTES;
+    int hrow[MT], hsw[MT];
+#pragma unroll
+    for (int b = 0; b < MT; ++b) {
+      hrow[b] = hr0[b] + dy * HWD + dx;
+      hsw[b] = (hrow[b] >> 1) & 7;
+    }
+    // fragment reads run two 16-deep sub-steps ahead of the MFMAs that consume them
+    bf16x8 xf[2][MT], wf[2][NT];
+#define MISEG_RD(KK)                                                                        \
+  {                                                                                         \
+    const int ch = (KK) * 2 + lhalf;                                                        \
+    _Pragma("unroll") for (int b = 0; b < MT; ++b) xf[(KK) & 1][b] =                        \
+        *reinterpret_cast<const bf16x8*>(hbase + hrow[b] * 128 + ((ch ^ hsw[b]) << 4));                                               \
+    _Pragma("unroll") for (int a = 0; a < NT; ++a) wf[(KK) & 1][a] =                        \
+        *reinterpret_cast<const bf16x8*>(wbase + swz128(wn * (NT * 32) + a * 32 + lrow, ch));                                               \
+  }
+    MISEG_RD(0)
+    MISEG_RD(1)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][a], xf[kk & 1][b],
+                                                              acc[a][b], 0, 0, 0);
+      if (kk + 2 < 4) MISEG_RD(kk + 2)
+    }
+#undef MISEG_RD
+  };
+
+#pragma unroll
+  for (int j = 0; j < NHW; ++j) issue_halo(j, 0, 0);
+  issue_w(0, 0, 0);
+  int chunk = 0, tap = 0, dy = 0, dx = 0;
+  for (int s = 0; s < steps; ++s) {
+#ifndef HALO_EXP_NOSYNC
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#endif
+    // next step's coordinates
+    int ntap = tap + 1, nchk = chunk;
+    if (ntap == 9) {
+      ntap = 0;
+      nchk = chunk + 1;
+    }
+#ifndef HALO_EXP_NOLOAD
+    if (s + 1 < steps) issue_w(ntap, nchk, (s + 1) & 1);
+#endif
+    if (HB == 2 && chunk + 1 < nchunk && tap < NHW) {
+      // one halo instruction of the next chunk per tap step
+#pragma unroll
+      for (int j = 0; j < NHW; ++j)
+        if (j == tap) issue_halo(j, chunk + 1, (chunk + 1) & 1);
+    }
+    compute(HB == 2 ? (chunk & 1) : 0, s & 1, dy, dx);
+    if (HB == 1 && tap == 8 && chunk + 1 < nchunk) {
+      __syncthreads();   // every wave is done with this chunk's halo
+#pragma unroll
+      for (int j = 0; j < NHW; ++j) issue_halo(j, chunk + 1, 0);
+    }
+    tap = ntap;
+    chunk = nchk;
+    if (++dx == 3) {
+      dx = 0;
+      if (++dy == 3) dy = 0;
+    }
+  }
+  const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+  conv_epilogue<WARPS_N, MT, NT>(p, tc, dec, acc, lds, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------
@@ -716,24 +947,55 @@ int validate_conv(const miseg_conv_desc* d) {
     set_error("conv: N*Ho*Wo=%lld exceeds 2^31", M);
     return MISEG_E_UNSUPPORTED_SHAPE;
   }
-  MISEG_CHECK_ARG(d->tile_hint >= 0 && (d->tile_hint & 15) <= (int)(sizeof(kCfgs) / sizeof(kCfgs[0])),
-                  "conv: bad tile_hint");
+  MISEG_CHECK_ARG(d->tile_hint >= 0 && (d->tile_hint & 15) <= 13, "conv: bad tile_hint");
   return MISEG_OK;
+}
+
+enum KernelKind { K_REG = 0, K_REG_PRO = 1, K_DMA = 2, K_HALO = 3 };
+struct KernelChoice {
+  KernelKind kind;
+  int cfg;  // 1..7 index into kCfgs; 8..10 halo variants
+};
+
+static KernelChoice choose_kernel(const miseg_conv_desc* d) {
+  const int hint = d->tile_hint & 15;
+  const bool pro = d->in_scale != nullptr;
+  const bool halo_ok = !pro && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride_y == 1 &&
+                       d->stride_x == 1 && d->pad_y == 1 && d->pad_x == 1 && d->Ho == d->H &&
+                       d->Wo == d->W && (d->Cin & 63) == 0 && !(d->tile_hint & MISEG_TILE_NO_HALO) &&
+                       !(d->tile_hint & MISEG_TILE_NO_DMA);
+  if (halo_ok && (hint == 0 || hint >= 8)) {
+    if (hint >= 8) return {K_HALO, hint};
+    if (d->Cout > 64) {
+      const long long blocks = (long long)d->N * ((d->Ho + 7) / 8) * ((d->Wo + 31) / 32) *
+                               ((d->Cout + 127) / 128);
+      // few, short blocks: the 8-wave 8x16 patch keeps more CUs busy; otherwise the 4-wave
+      // 8x32 patch with 128x64 wave tiles (two blocks per CU) has the best MFMA density
+      return {K_HALO, (blocks >= 512 || d->Cin >= 512) ? 11 : 10};
+    }
+    if (d->Cout > 32) return {K_HALO, 12};
+  }
+  const int M = d->N * d->Ho * d->Wo;
+  const int cfg = (hint >= 1 && hint <= 7) ? hint : choose_cfg(M, d->Cout);
+  if (pro) return {K_REG_PRO, cfg};
+  if ((d->Cin & 63) == 0 && !(d->tile_hint & MISEG_TILE_NO_DMA)) return {K_DMA, cfg};
+  return {K_REG, cfg};
 }
 
 // Name of the kernel instantiation launch_conv() picks for `d`, as rocprofv3 prints it.
 void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
-  const int hint = d->tile_hint & 15;
-  const int M = d->N * d->Ho * d->Wo;
-  const int cfg = hint ? hint : choose_cfg(M, d->Cout);
+  const KernelChoice kc = choose_kernel(d);
   static const char* shapes[] = {"2, 2, 2, 2", "4, 1, 2, 2", "4, 1, 2, 1", "2, 2, 1, 1",
                                  "4, 1, 1, 2", "4, 1, 1, 1", "2, 2, 1, 2"};
-  const bool pro = d->in_scale != nullptr;
-  const bool dma = !pro && (d->Cin & 63) == 0 && !(d->tile_hint & MISEG_TILE_NO_DMA);
-  if (dma)
-    snprintf(buf, len, "conv_igemm_dma_kernel<%s>", shapes[cfg - 1]);
+  static const char* halos[] = {"8, 32, 4, 2, 2, 2, 2", "8, 32, 4, 2, 2, 1, 2", "8, 16, 4, 2, 1, 2, 2",
+                                "8, 32, 2, 2, 4, 2, 1", "8, 32, 4, 1, 2, 2, 1", "8, 16, 2, 2, 2, 2, 2"};
+  if (kc.kind == K_HALO)
+    snprintf(buf, len, "conv3x3_halo_kernel<%s>", halos[kc.cfg - 8]);
+  else if (kc.kind == K_DMA)
+    snprintf(buf, len, "conv_igemm_dma_kernel<%s>", shapes[kc.cfg - 1]);
   else
-    snprintf(buf, len, "conv_igemm_kernel<%s, %s>", shapes[cfg - 1], pro ? "true" : "false");
+    snprintf(buf, len, "conv_igemm_kernel<%s, %s>", shapes[kc.cfg - 1],
+             kc.kind == K_REG_PRO ? "true" : "false");
 }
 
 int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
@@ -770,14 +1032,24 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   p.inv_temperature = d->act == MISEG_ACT_SOFTMAX ? 1.f / d->temperature : 1.f;
   p.collapse_value = d->collapse_value;
   p.M = d->N * d->Ho * d->Wo;
-  const int hint = d->tile_hint & 15;
-  const int cfg = hint ? hint : choose_cfg(p.M, d->Cout);
-  const TileCfg tc = kCfgs[cfg - 1];
-  p.mtiles = (p.M + tc.bm - 1) / tc.bm;
-  p.ntiles = (d->Cout + tc.bn - 1) / tc.bn;
+  const KernelChoice kc = choose_kernel(d);
+  const int cfg = kc.cfg;
+  const bool pro = kc.kind == K_REG_PRO;
+  const bool dma = kc.kind == K_DMA;
+  p.tiles_y = p.tiles_x = 0;
+  if (kc.kind == K_HALO) {
+    const int tw = (cfg == 10 || cfg == 13) ? 16 : 32;
+    const int bn = (cfg == 9 || cfg == 12) ? 64 : 128;
+    p.tiles_y = (d->Ho + 7) / 8;
+    p.tiles_x = (d->Wo + tw - 1) / tw;
+    p.mtiles = d->N * p.tiles_y * p.tiles_x;
+    p.ntiles = (d->Cout + bn - 1) / bn;
+  } else {
+    const TileCfg tc = kCfgs[cfg - 1];
+    p.mtiles = (p.M + tc.bm - 1) / tc.bm;
+    p.ntiles = (d->Cout + tc.bn - 1) / tc.bn;
+  }
   const dim3 grid(p.mtiles * p.ntiles, d->transposed ? 4 : 1, 1);
-  const bool pro = d->in_scale != nullptr;
-  const bool dma = !pro && (d->Cin & 63) == 0 && !(d->tile_hint & MISEG_TILE_NO_DMA);
   auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
     return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
   };
@@ -800,7 +1072,31 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     case 4: e = launch_cfg<2, 2, 1, 1>(p, grid, pro, dma, stream); break;
     case 5: e = launch_cfg<4, 1, 1, 2>(p, grid, pro, dma, stream); break;
     case 6: e = launch_cfg<4, 1, 1, 1>(p, grid, pro, dma, stream); break;
-    default: e = launch_cfg<2, 2, 1, 2>(p, grid, pro, dma, stream); break;
+    case 7: e = launch_cfg<2, 2, 1, 2>(p, grid, pro, dma, stream); break;
+    case 8:
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 2, 2, 2, 2>), grid, dim3(512), 0, stream, p);
+      e = hipGetLastError();
+      break;
+    case 9:
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 2, 2, 1, 2>), grid, dim3(512), 0, stream, p);
+      e = hipGetLastError();
+      break;
+    case 10:
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 16, 4, 2, 1, 2, 2>), grid, dim3(512), 0, stream, p);
+      e = hipGetLastError();
+      break;
+    case 11:
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 2, 2, 4, 2, 1>), grid, dim3(256), 0, stream, p);
+      e = hipGetLastError();
+      break;
+    case 12:
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 1, 2, 2, 1>), grid, dim3(256), 0, stream, p);
+      e = hipGetLastError();
+      break;
+    default:
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 16, 2, 2, 2, 2, 2>), grid, dim3(256), 0, stream, p);
+      e = hipGetLastError();
+      break;
   }
   if (e != hipSuccess) {
     set_error("conv launch failed: %s", hipGetErrorString(e));

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmiseg.so")
+LIB_PATH = os.environ.get("MISEG_LIB") or os.path.join(_HERE, "libmiseg.so")   # MISEG_LIB: experiments
 
 OK = 0
 DT_BF16, DT_F32 = 0, 1

@@ -113,14 +113,18 @@ CASES = [
     (1, 10, 14, 32, 64, 1, 2, 0),      # shortcut conv
     (1, 8, 8, 128, 256, 3, 1, 1),
     (1, 20, 12, 32, 8, 3, 1, 1),       # narrow cout
+    (1, 20, 70, 64, 96, 3, 1, 1),      # several patches per row, ragged right/bottom edge
+    (2, 17, 33, 128, 128, 3, 1, 1),    # two channel chunks, odd sizes
+    (1, 8, 32, 192, 64, 3, 1, 1),      # exactly one patch, three chunks
 ]
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 32])
 def test_conv_plain(env, case, hint):
-    """hint & 15 picks the tile shape; hint & 16 forces the register-staged path where the
-    LDS-DMA path (Cin % 64 == 0) would be chosen."""
+    """hint & 15 picks the tile shape (8..10: halo-resident 3x3 variants, used where the
+    layer qualifies); hint & 16 forces the register-staged path where an LDS-DMA path
+    (Cin % 64 == 0) would be chosen; hint & 32 keeps 3x3 layers off the halo kernel."""
     n, h, w, cin, cout, k, stride, pad = case
     rng = np.random.default_rng(hash(case) % 2**32)
     x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
