@@ -153,12 +153,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
   const int px_l = lane / LPP;
   const int co_l = (lane % LPP) * 8;
   const int co = tc.cout0 + wn * TNW + co_l;
-  const bool co_any = co < p.Cout;
   const bool full = co + 8 <= p.Cout && p.vec_ok;
+  const bool head = p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID;
 
   static_for<MT>([&](auto bc) __attribute__((always_inline)) {
     constexpr int b = decltype(bc)::value;
-    __syncthreads();
+    // The region is private to this wave and a wave's LDS operations execute in order, so
+    // no workgroup barrier is needed between the transposing writes and the reads below,
+    // nor before the next tile overwrites the region: only the compiler must keep the order.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -166,39 +170,49 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
         *reinterpret_cast<float4*>(ep + lrow * ROWF + a * 32 + 8 * g + 4 * lhalf) =
             make_float4(acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2],
                         acc[a][b][4 * g + 3]);
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-      const int px = ps * PPP + px_l;
+      int px = ps * PPP + px_l;
+      int co_lx = co_l;
+      if (head) {
+        // softmax / sigmoid head (Cout <= 4): one pixel per lane, one pass
+        if (ps != 0 || lane >= 32) continue;
+        px = lane;
+        co_lx = 0;
+      }
+      const int cox = tc.cout0 + wn * TNW + co_lx;
+      const bool fullx = !head && full;
       int n, oy, ox, rem;
-      if (!co_any || !decode(wm * (MT * 32) + b * 32 + px, n, oy, ox, rem)) continue;
+      if (cox >= p.Cout || !decode(wm * (MT * 32) + b * 32 + px, n, oy, ox, rem)) continue;
       if (p.transposed) {
         oy = 2 * oy + tc.ph_a;
         ox = 2 * ox + tc.ph_b;
       }
       float v[8];
       {
-        const float4 v0 = *reinterpret_cast<const float4*>(ep + px * ROWF + co_l);
-        const float4 v1 = *reinterpret_cast<const float4*>(ep + px * ROWF + co_l + 4);
+        const float4 v0 = *reinterpret_cast<const float4*>(ep + px * ROWF + co_lx);
+        const float4 v1 = *reinterpret_cast<const float4*>(ep + px * ROWF + co_lx + 4);
         v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
         v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
       }
       const long long o_off = n * p.out_img_stride + (long long)oy * p.out_row_stride +
-                              (long long)ox * p.out_pix_stride + co;
+                              (long long)ox * p.out_pix_stride + cox;
       const long long o2_off = n * p.out2_img_stride + (long long)oy * p.out2_row_stride +
-                               (long long)ox * p.out2_pix_stride + co;
+                               (long long)ox * p.out2_pix_stride + cox;
       const long long r_off = n * p.res_img_stride + (long long)oy * p.res_row_stride +
-                              (long long)ox * p.res_pix_stride + co;
-      if (full) {
+                              (long long)ox * p.res_pix_stride + cox;
+      if (fullx) {
         if (p.scale) {
-          const float4 s0 = *reinterpret_cast<const float4*>(p.scale + co);
-          const float4 s1 = *reinterpret_cast<const float4*>(p.scale + co + 4);
+          const float4 s0 = *reinterpret_cast<const float4*>(p.scale + cox);
+          const float4 s1 = *reinterpret_cast<const float4*>(p.scale + cox + 4);
           v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w;
           v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
         }
         if (p.shift) {
-          const float4 s0 = *reinterpret_cast<const float4*>(p.shift + co);
-          const float4 s1 = *reinterpret_cast<const float4*>(p.shift + co + 4);
+          const float4 s0 = *reinterpret_cast<const float4*>(p.shift + cox);
+          const float4 s1 = *reinterpret_cast<const float4*>(p.shift + cox + 4);
           v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w;
           v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
         }
@@ -233,10 +247,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
           }
         }
         if (p.out2) {
-          const float4 s0 = *reinterpret_cast<const float4*>(p.scale2 + co);
-          const float4 s1 = *reinterpret_cast<const float4*>(p.scale2 + co + 4);
-          const float4 t0 = *reinterpret_cast<const float4*>(p.shift2 + co);
-          const float4 t1 = *reinterpret_cast<const float4*>(p.shift2 + co + 4);
+          const float4 s0 = *reinterpret_cast<const float4*>(p.scale2 + cox);
+          const float4 s1 = *reinterpret_cast<const float4*>(p.scale2 + cox + 4);
+          const float4 t0 = *reinterpret_cast<const float4*>(p.shift2 + cox);
+          const float4 t1 = *reinterpret_cast<const float4*>(p.shift2 + cox + 4);
           *reinterpret_cast<uint4*>(p.out2 + o2_off) = make_uint4(
               pack_bf16x2(fmaxf(v[0] * s0.x + t0.x, 0.f), fmaxf(v[1] * s0.y + t0.y, 0.f)),
               pack_bf16x2(fmaxf(v[2] * s0.z + t0.z, 0.f), fmaxf(v[3] * s0.w + t0.w, 0.f)),
@@ -248,9 +262,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
       // ---- partial channel group (Cout tail, unaligned strides, or the softmax head) ----
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (co + j < p.Cout) {
-          if (p.scale) v[j] *= p.scale[co + j];
-          if (p.shift) v[j] += p.shift[co + j];
+        if (cox + j < p.Cout) {
+          if (p.scale) v[j] *= p.scale[cox + j];
+          if (p.shift) v[j] += p.shift[cox + j];
           if (has_res)
             v[j] += p.res_dtype == MISEG_DT_F32
                         ? reinterpret_cast<const float*>(p.residual)[r_off + j]
@@ -258,7 +272,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
         }
       }
       if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID) {
-        // Cout <= 4: the whole channel vector of this pixel sits in this lane (co == 0).
+        // Cout <= 4: the whole channel vector of this pixel sits in this lane (cox == 0).
         const int C = p.Cout;
         float pr[4];
         if (p.act == MISEG_ACT_SIGMOID) {
@@ -308,7 +322,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (co + j >= p.Cout) continue;
+        if (cox + j >= p.Cout) continue;
         if (p.out) {
           const float w = p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
           if (p.out_dtype == MISEG_DT_F32)
@@ -317,7 +331,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
             reinterpret_cast<bf16_t*>(p.out)[o_off + j] = f32_to_bf16(w);
         }
         if (p.out2)
-          p.out2[o2_off + j] = f32_to_bf16(fmaxf(v[j] * p.scale2[co + j] + p.shift2[co + j], 0.f));
+          p.out2[o2_off + j] = f32_to_bf16(fmaxf(v[j] * p.scale2[cox + j] + p.shift2[cox + j], 0.f));
       }
     }
   });
@@ -489,6 +503,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
   const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
+  __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
   conv_epilogue<WARPS_N, MT, NT>(p, tc, dec, acc, lds, wm, wn, lane);
 }
 
@@ -630,6 +645,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     compute(ks & 1);
   }
   const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
+  __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
   conv_epilogue<WARPS_N, MT, NT>(p, tc, dec, acc, lds, wm, wn, lane);
 }
 
@@ -829,7 +845,115 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
     }
   }
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+  __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
   conv_epilogue<WARPS_N, MT, NT>(p, tc, dec, acc, lds, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------
+// Kernel D: 3x3, stride 1, pad 1, Cin = 32, Cout <= 32 (the full-resolution decoder conv
+// and the segmentation head).  These layers are bandwidth-bound: a block brings the
+// (TH+2) x (TW+2) x 32 halo and all nine 32x32 weight taps into LDS with one LDS-DMA burst,
+// synchronises once, and runs the 9 x 2 MFMA sub-steps without further barriers; four
+// blocks per CU overlap each other's load, compute and store phases.  (A persistent
+// variant with the weights resident and the next halo prefetched measured no faster: two
+// 80 KB blocks per CU keep fewer bytes in flight than four 40 KB ones.)
+// ---------------------------------------------------------------------------------
+template <int TH, int TW>
+__global__ __launch_bounds__(256) void conv3x3_c32_kernel(const ConvParams p) {
+  constexpr int BM = TH * TW;
+  constexpr int MT = BM / 128;
+  static_assert(BM % 128 == 0, "patch must split over 4 waves of 32-pixel tiles");
+  constexpr int HWD = TW + 2;
+  constexpr int HROWS = (TH + 2) * HWD;
+  constexpr int NHI = (HROWS + 15) / 16;   // wave-instructions of 16 rows x 64 B
+  constexpr int NHW = (NHI + 3) / 4;
+  constexpr int HALO_BYTES = NHI * 1024;
+  constexpr int NWI = 9 * 32 / 16;
+  constexpr int NWW = (NWI + 3) / 4;
+  constexpr int W_BYTES = NWI * 1024;
+  constexpr int EPI = 4 * 32 * (32 + 4) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[cmax(HALO_BYTES + W_BYTES, EPI)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const TileCoord tc = tile_coord<BM, 32>(p);
+  const int mtile = tc.m0 / BM;
+  const int per_img = p.tiles_y * p.tiles_x;
+  const int n = mtile / per_img;
+  const int trem = mtile - n * per_img;
+  const int tyi = trem / p.tiles_x;
+  const int y0 = tyi * TH;
+  const int x0 = (trem - tyi * p.tiles_x) * TW;
+  const int r16 = lane >> 2;
+  const int slot = lane & 3;
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line) + slot * 8;
+
+#pragma unroll
+  for (int j = 0; j < NHW; ++j) {
+    const int i = j * 4 + wave;
+    if (i < NHI) {
+      const int hr = i * 16 + r16;
+      const int hy = hr / HWD;
+      const int hx = hr - hy * HWD;
+      const int iy = y0 - 1 + hy;
+      const int ix = x0 - 1 + hx;
+      const bool ok = hr < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int ch = slot ^ ((hr >> 2) & 3);
+      const bf16_t* src = ok ? p.in + n * p.in_img_stride + (long long)iy * p.in_row_stride +
+                                   (long long)ix * p.in_pix_stride + ch * 8
+                             : zero_src;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(lds + i * 1024),
+                                       16, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NWW; ++j) {
+    const int i = j * 4 + wave;
+    if (i < NWI) {
+      const int wr = i * 16 + r16;      // LDS row = tap * 32 + cout
+      const int tap = wr >> 5;
+      const int co = wr & 31;
+      const int ch = slot ^ ((wr >> 2) & 3);
+      const bf16_t* src = co < p.Cout ? tc.wbase + ((long long)co * 9 + tap) * 32 + ch * 8 : zero_src;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(lds + HALO_BYTES + i * 1024), 16, 0, 0);
+    }
+  }
+
+  f32x16 acc[1][MT];
+  zero_acc<MT, 1>(acc);
+  const int lrow = lane & 31;
+  const int lhalf = lane >> 5;
+  int hr0[MT];
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    const int pidx = (wave * MT + b) * 32 + lrow;
+    hr0[b] = (pidx / TW) * HWD + (pidx % TW);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int ch = kk * 2 + lhalf;
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + HALO_BYTES + swz64(tap * 32 + lrow, ch));
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        const int hrow = hr0[b] + dy * HWD + dx;
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + swz64(hrow, ch));
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[0][b], 0, 0, 0);
+      }
+    }
+  }
+  const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+  __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
+  conv_epilogue<1, MT, 1>(p, tc, dec, acc, lds, wave, 0, lane);
 }
 
 // ---------------------------------------------------------------------------------
@@ -947,11 +1071,11 @@ int validate_conv(const miseg_conv_desc* d) {
     set_error("conv: N*Ho*Wo=%lld exceeds 2^31", M);
     return MISEG_E_UNSUPPORTED_SHAPE;
   }
-  MISEG_CHECK_ARG(d->tile_hint >= 0 && (d->tile_hint & 15) <= 13, "conv: bad tile_hint");
+  MISEG_CHECK_ARG(d->tile_hint >= 0 && (d->tile_hint & 15) <= 14, "conv: bad tile_hint");
   return MISEG_OK;
 }
 
-enum KernelKind { K_REG = 0, K_REG_PRO = 1, K_DMA = 2, K_HALO = 3 };
+enum KernelKind { K_REG = 0, K_REG_PRO = 1, K_DMA = 2, K_HALO = 3, K_C32 = 4 };
 struct KernelChoice {
   KernelKind kind;
   int cfg;  // 1..7 index into kCfgs; 8..10 halo variants
@@ -964,7 +1088,12 @@ static KernelChoice choose_kernel(const miseg_conv_desc* d) {
                        d->stride_x == 1 && d->pad_y == 1 && d->pad_x == 1 && d->Ho == d->H &&
                        d->Wo == d->W && (d->Cin & 63) == 0 && !(d->tile_hint & MISEG_TILE_NO_HALO) &&
                        !(d->tile_hint & MISEG_TILE_NO_DMA);
-  if (halo_ok && (hint == 0 || hint >= 8)) {
+  const bool c32_ok = !pro && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride_y == 1 &&
+                      d->stride_x == 1 && d->pad_y == 1 && d->pad_x == 1 && d->Ho == d->H &&
+                      d->Wo == d->W && d->Cin == 32 && d->Cout <= 32 &&
+                      !(d->tile_hint & MISEG_TILE_NO_HALO);
+  if (c32_ok && (hint == 0 || hint == 14)) return {K_C32, 14};
+  if (halo_ok && (hint == 0 || (hint >= 8 && hint <= 13))) {
     if (hint >= 8) return {K_HALO, hint};
     if (d->Cout > 64) {
       const long long blocks = (long long)d->N * ((d->Ho + 7) / 8) * ((d->Wo + 31) / 32) *
@@ -989,7 +1118,9 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
                                  "4, 1, 1, 2", "4, 1, 1, 1", "2, 2, 1, 2"};
   static const char* halos[] = {"8, 32, 4, 2, 2, 2, 2", "8, 32, 4, 2, 2, 1, 2", "8, 16, 4, 2, 1, 2, 2",
                                 "8, 32, 2, 2, 4, 2, 1", "8, 32, 4, 1, 2, 2, 1", "8, 16, 2, 2, 2, 2, 2"};
-  if (kc.kind == K_HALO)
+  if (kc.kind == K_C32)
+    snprintf(buf, len, "conv3x3_c32_kernel<8, 32>");
+  else if (kc.kind == K_HALO)
     snprintf(buf, len, "conv3x3_halo_kernel<%s>", halos[kc.cfg - 8]);
   else if (kc.kind == K_DMA)
     snprintf(buf, len, "conv_igemm_dma_kernel<%s>", shapes[kc.cfg - 1]);
@@ -1037,7 +1168,12 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   const bool pro = kc.kind == K_REG_PRO;
   const bool dma = kc.kind == K_DMA;
   p.tiles_y = p.tiles_x = 0;
-  if (kc.kind == K_HALO) {
+  if (kc.kind == K_C32) {
+    p.tiles_y = (d->Ho + 7) / 8;
+    p.tiles_x = (d->Wo + 31) / 32;
+    p.mtiles = d->N * p.tiles_y * p.tiles_x;
+    p.ntiles = 1;
+  } else if (kc.kind == K_HALO) {
     const int tw = (cfg == 10 || cfg == 13) ? 16 : 32;
     const int bn = (cfg == 9 || cfg == 12) ? 64 : 128;
     p.tiles_y = (d->Ho + 7) / 8;
@@ -1093,8 +1229,12 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
       hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 1, 2, 2, 1>), grid, dim3(256), 0, stream, p);
       e = hipGetLastError();
       break;
-    default:
+    case 13:
       hipLaunchKernelGGL((conv3x3_halo_kernel<8, 16, 2, 2, 2, 2, 2>), grid, dim3(256), 0, stream, p);
+      e = hipGetLastError();
+      break;
+    default:
+      hipLaunchKernelGGL((conv3x3_c32_kernel<8, 32>), grid, dim3(256), 0, stream, p);
       e = hipGetLastError();
       break;
   }

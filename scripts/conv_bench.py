@@ -12,6 +12,8 @@ ap.add_argument("--hint", type=int, default=0)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--transposed", action="store_true")
 ap.add_argument("--relu", action="store_true")
+ap.add_argument("--softmax", action="store_true")
+ap.add_argument("--f32out", action="store_true")
 a = ap.parse_args()
 n, h, w, cin, cout, k = a.dims[:6]
 stride = a.dims[6] if len(a.dims) > 6 else 1
@@ -40,6 +42,15 @@ d.pad_y = d.pad_x = pad
 d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin, cin * w, cin * w * h
 d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * ow, cout * ow * oh
 d.act = 1 if a.relu else 0
+if a.softmax or a.f32out:
+    out = torch.zeros((n, oh, ow, cout), dtype=torch.float32, device=dev)
+    d.out = out.data_ptr()
+    d.out_dtype = L.DT_F32
+if a.softmax:
+    mask = torch.zeros((n, oh, ow, cout), dtype=torch.uint8, device=dev)
+    d.act = L.ACT_SOFTMAX
+    d.collapse_out = mask.data_ptr()
+    d.collapse_value = 127
 d.transposed = 1 if a.transposed else 0
 d.temperature = 1.0
 d.tile_hint = a.hint

@@ -120,7 +120,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 18, 19, 20, 21, 22, 23, 32])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 32])
 def test_conv_plain(env, case, hint):
     """hint & 15 picks the tile shape (8..10: halo-resident 3x3 variants, used where the
     layer qualifies); hint & 16 forces the register-staged path where an LDS-DMA path
