@@ -103,7 +103,7 @@ typedef struct miseg_conv_desc {
   int32_t transposed;
   float temperature;       /* MISEG_ACT_SOFTMAX: logits are divided by it */
   int32_t collapse_value;  /* value written for the winning channel (127) */
-  int32_t tile_hint;       /* 0 = choose automatically; low 4 bits = tile config 1..14,
+  int32_t tile_hint;       /* 0 = choose automatically; low 4 bits = tile config 1..15,
                               | MISEG_TILE_NO_DMA forces the register-staged path (tests) */
 } miseg_conv_desc;
 

@@ -91,11 +91,16 @@ __device__ __forceinline__ TileCoord tile_coord(const ConvParams& p) {
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each of the 8
   // groups a contiguous run of tiles, with the N-tiles of one M-tile adjacent.
   TileCoord t;
-  const int ntot = p.mtiles * p.ntiles;
+  // For transpose-conv the four phases of one tile are consecutive work items, so they run
+  // on the same XCD at about the same time and their interleaved output pixels merge in L2.
+  const int nph = p.transposed ? 4 : 1;
+  const int ntot = p.mtiles * p.ntiles * nph;
   const int bid = blockIdx.x;
   const int q = ntot >> 3, r = ntot & 7;
   const int x = bid & 7, loc = bid >> 3;
-  const int tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+  const int item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+  const int phase = p.transposed ? (item & 3) : 0;
+  const int tile = p.transposed ? (item >> 2) : item;
   const int mtile = tile / p.ntiles;
   const int ntile = tile - mtile * p.ntiles;
   t.m0 = mtile * BM;
@@ -105,7 +110,6 @@ __device__ __forceinline__ TileCoord tile_coord(const ConvParams& p) {
   t.ph_a = t.ph_b = 0;
   t.wbase = p.weight;
   if (p.transposed) {
-    const int phase = blockIdx.y;
     t.ph_a = phase >> 1;
     t.ph_b = phase & 1;
     t.pad_y = 1 - t.ph_a;
@@ -671,8 +675,12 @@ struct PatchDecode {
   }
 };
 
-template <int TH, int TW, int WARPS_M, int WARPS_N, int MT, int NT, int HB>
+template <int TH, int TW, int WARPS_M, int WARPS_N, int MT, int NT, int HB, bool CONVT>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(const ConvParams p) {
+  // CONVT: one phase (a,b) of Conv2DTranspose(4, 2, 'same'): a 2x2 convolution whose taps
+  // (dy,dx) read halo pixel (y + a + dy, x + b + dx); same halo, four taps per chunk.
+  constexpr int TAPS = CONVT ? 4 : 9;
+  constexpr int TAPW = CONVT ? 2 : 3;
   // HB = 2: halo double buffered (next chunk fetched during the current one's taps);
   // HB = 1: one halo buffer, refilled between chunks -- half the LDS, so two blocks share a
   //         CU and cover each other's refill.
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
   constexpr int HROWS = (TH + 2) * HWD;          // halo pixels, one 128-B LDS row each
   constexpr int NHI = (HROWS + 7) / 8;           // halo wave-instructions per chunk
   constexpr int NHW = (NHI + NW - 1) / NW;       // ... per wave
-  static_assert(HB == 1 || NHW <= 9, "next halo must fit in the nine tap steps of a chunk");
+  static_assert(HB == 1 || NHW <= TAPS, "next halo must fit in the tap steps of a chunk");
   constexpr int HALO_BYTES = NHI * 1024;
   constexpr int NBI = BN / 8;                    // weight wave-instructions per K-step
   constexpr int NBW = (NBI + NW - 1) / NW;
@@ -709,7 +717,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
   const int x0 = (trem - tyi * p.tiles_x) * TW;
 
   const int nchunk = p.Cin >> 6;
-  const int steps = nchunk * 9;
+  const int steps = nchunk * TAPS;
   const int r8 = lane >> 3;
   const int slot = lane & 7;
   const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line) + slot * 8;
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
     const int row = (j * NW + wave) * 8 + r8;
     const int co = tc.cout0 + row;
     const int ch = slot ^ ((row >> 1) & 7);
-    w_src[j] = (row < BN && co < p.Cout) ? tc.wbase + (long long)co * 9 * p.Cin + ch * 8 : nullptr;
+    w_src[j] = (row < BN && co < p.Cout) ? tc.wbase + (long long)co * TAPS * p.Cin + ch * 8 : nullptr;
   }
 
   auto issue_halo = [&](int j, int chunk, int hb) {
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
 #pragma unroll
   for (int b = 0; b < MT; ++b) {
     const int pidx = (wm * MT + b) * 32 + lrow;
-    hr0[b] = (pidx / TW) * HWD + (pidx % TW);
+    hr0[b] = (pidx / TW + (CONVT ? tc.ph_a : 0)) * HWD + (pidx % TW) + (CONVT ? tc.ph_b : 0);
   }
 
   auto compute = [&](int hb, int wb, int dy, int dx) __attribute__((always_inline)) {
@@ -818,7 +826,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
 #endif
     // next step's coordinates
     int ntap = tap + 1, nchk = chunk;
-    if (ntap == 9) {
+    if (ntap == TAPS) {
       ntap = 0;
       nchk = chunk + 1;
     }
@@ -832,16 +840,16 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
         if (j == tap) issue_halo(j, chunk + 1, (chunk + 1) & 1);
     }
     compute(HB == 2 ? (chunk & 1) : 0, s & 1, dy, dx);
-    if (HB == 1 && tap == 8 && chunk + 1 < nchunk) {
+    if (HB == 1 && tap == TAPS - 1 && chunk + 1 < nchunk) {
       __syncthreads();   // every wave is done with this chunk's halo
 #pragma unroll
       for (int j = 0; j < NHW; ++j) issue_halo(j, chunk + 1, 0);
     }
     tap = ntap;
     chunk = nchk;
-    if (++dx == 3) {
+    if (++dx == TAPW) {
       dx = 0;
-      if (++dy == 3) dy = 0;
+      if (++dy == TAPW) dy = 0;
     }
   }
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
@@ -1071,7 +1079,7 @@ int validate_conv(const miseg_conv_desc* d) {
     set_error("conv: N*Ho*Wo=%lld exceeds 2^31", M);
     return MISEG_E_UNSUPPORTED_SHAPE;
   }
-  MISEG_CHECK_ARG(d->tile_hint >= 0 && (d->tile_hint & 15) <= 14, "conv: bad tile_hint");
+  MISEG_CHECK_ARG(d->tile_hint >= 0 && (d->tile_hint & 15) <= 15, "conv: bad tile_hint");
   return MISEG_OK;
 }
 
@@ -1093,7 +1101,13 @@ static KernelChoice choose_kernel(const miseg_conv_desc* d) {
                       d->Wo == d->W && d->Cin == 32 && d->Cout <= 32 &&
                       !(d->tile_hint & MISEG_TILE_NO_HALO);
   if (c32_ok && (hint == 0 || hint == 14)) return {K_C32, 14};
-  if (halo_ok && (hint == 0 || (hint >= 8 && hint <= 13))) {
+  const bool convt_ok = !pro && d->transposed && (d->Cin & 63) == 0 &&
+                        !(d->tile_hint & MISEG_TILE_NO_HALO) && !(d->tile_hint & MISEG_TILE_NO_DMA);
+  if (convt_ok && (hint == 0 || hint == 11 || hint == 12 || hint == 15)) {
+    if (hint) return {K_HALO, hint};
+    return {K_HALO, d->Cout > 64 ? 11 : (d->Cout > 32 ? 12 : 15)};
+  }
+  if (halo_ok && (hint == 0 || (hint >= 8 && hint <= 13) || hint == 15)) {
     if (hint >= 8) return {K_HALO, hint};
     if (d->Cout > 64) {
       const long long blocks = (long long)d->N * ((d->Ho + 7) / 8) * ((d->Wo + 31) / 32) *
@@ -1103,6 +1117,7 @@ static KernelChoice choose_kernel(const miseg_conv_desc* d) {
       return {K_HALO, (blocks >= 512 || d->Cin >= 512) ? 11 : 10};
     }
     if (d->Cout > 32) return {K_HALO, 12};
+    return {K_HALO, 15};
   }
   const int M = d->N * d->Ho * d->Wo;
   const int cfg = (hint >= 1 && hint <= 7) ? hint : choose_cfg(M, d->Cout);
@@ -1117,11 +1132,12 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
   static const char* shapes[] = {"2, 2, 2, 2", "4, 1, 2, 2", "4, 1, 2, 1", "2, 2, 1, 1",
                                  "4, 1, 1, 2", "4, 1, 1, 1", "2, 2, 1, 2"};
   static const char* halos[] = {"8, 32, 4, 2, 2, 2, 2", "8, 32, 4, 2, 2, 1, 2", "8, 16, 4, 2, 1, 2, 2",
-                                "8, 32, 2, 2, 4, 2, 1", "8, 32, 4, 1, 2, 2, 1", "8, 16, 2, 2, 2, 2, 2"};
+                                "8, 32, 2, 2, 4, 2, 1", "8, 32, 4, 1, 2, 2, 1", "8, 16, 2, 2, 2, 2, 2",
+                                "", "8, 32, 4, 1, 2, 1, 1"};
   if (kc.kind == K_C32)
     snprintf(buf, len, "conv3x3_c32_kernel<8, 32>");
   else if (kc.kind == K_HALO)
-    snprintf(buf, len, "conv3x3_halo_kernel<%s>", halos[kc.cfg - 8]);
+    snprintf(buf, len, "conv3x3_halo_kernel<%s, %s>", halos[kc.cfg - 8], d->transposed ? "true" : "false");
   else if (kc.kind == K_DMA)
     snprintf(buf, len, "conv_igemm_dma_kernel<%s>", shapes[kc.cfg - 1]);
   else
@@ -1175,7 +1191,7 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     p.ntiles = 1;
   } else if (kc.kind == K_HALO) {
     const int tw = (cfg == 10 || cfg == 13) ? 16 : 32;
-    const int bn = (cfg == 9 || cfg == 12) ? 64 : 128;
+    const int bn = cfg == 15 ? 32 : ((cfg == 9 || cfg == 12) ? 64 : 128);
     p.tiles_y = (d->Ho + 7) / 8;
     p.tiles_x = (d->Wo + tw - 1) / tw;
     p.mtiles = d->N * p.tiles_y * p.tiles_x;
@@ -1185,7 +1201,7 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     p.mtiles = (p.M + tc.bm - 1) / tc.bm;
     p.ntiles = (d->Cout + tc.bn - 1) / tc.bn;
   }
-  const dim3 grid(p.mtiles * p.ntiles, d->transposed ? 4 : 1, 1);
+  const dim3 grid(p.mtiles * p.ntiles * (d->transposed ? 4 : 1), 1, 1);
   auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
     return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
   };
@@ -1210,27 +1226,40 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     case 6: e = launch_cfg<4, 1, 1, 1>(p, grid, pro, dma, stream); break;
     case 7: e = launch_cfg<2, 2, 1, 2>(p, grid, pro, dma, stream); break;
     case 8:
-      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 2, 2, 2, 2>), grid, dim3(512), 0, stream, p);
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 2, 2, 2, 2, false>), grid, dim3(512), 0, stream, p);
       e = hipGetLastError();
       break;
     case 9:
-      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 2, 2, 1, 2>), grid, dim3(512), 0, stream, p);
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 2, 2, 1, 2, false>), grid, dim3(512), 0, stream, p);
       e = hipGetLastError();
       break;
     case 10:
-      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 16, 4, 2, 1, 2, 2>), grid, dim3(512), 0, stream, p);
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 16, 4, 2, 1, 2, 2, false>), grid, dim3(512), 0, stream, p);
       e = hipGetLastError();
       break;
     case 11:
-      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 2, 2, 4, 2, 1>), grid, dim3(256), 0, stream, p);
+      if (d->transposed)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 2, 2, 4, 2, 1, true>), grid, dim3(256), 0, stream, p);
+      else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 2, 2, 4, 2, 1, false>), grid, dim3(256), 0, stream, p);
       e = hipGetLastError();
       break;
     case 12:
-      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 1, 2, 2, 1>), grid, dim3(256), 0, stream, p);
+      if (d->transposed)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 1, 2, 2, 1, true>), grid, dim3(256), 0, stream, p);
+      else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 1, 2, 2, 1, false>), grid, dim3(256), 0, stream, p);
+      e = hipGetLastError();
+      break;
+    case 15:
+      if (d->transposed)
+        hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 1, 2, 1, 1, true>), grid, dim3(256), 0, stream, p);
+      else
+        hipLaunchKernelGGL((conv3x3_halo_kernel<8, 32, 4, 1, 2, 1, 1, false>), grid, dim3(256), 0, stream, p);
       e = hipGetLastError();
       break;
     case 13:
-      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 16, 2, 2, 2, 2, 2>), grid, dim3(256), 0, stream, p);
+      hipLaunchKernelGGL((conv3x3_halo_kernel<8, 16, 2, 2, 2, 2, 2, false>), grid, dim3(256), 0, stream, p);
       e = hipGetLastError();
       break;
     default:

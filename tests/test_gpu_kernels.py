@@ -120,7 +120,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23, 32])
+@pytest.mark.parametrize("hint", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 32])
 def test_conv_plain(env, case, hint):
     """hint & 15 picks the tile shape (8..10: halo-resident 3x3 variants, used where the
     layer qualifies); hint & 16 forces the register-staged path where an LDS-DMA path
@@ -175,11 +175,16 @@ def test_conv_prologue(env, k, pad):
     np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3 * np.abs(want).max())
 
 
-def test_conv_transpose_4x4s2(env):
+@pytest.mark.parametrize("shape", [(2, 6, 7, 64, 32), (1, 9, 35, 128, 64), (1, 8, 32, 64, 160),
+                                   (2, 5, 5, 32, 16), (1, 17, 40, 192, 128)])
+@pytest.mark.parametrize("hint", [0, 11, 12, 15, 16, 32])
+def test_conv_transpose_4x4s2(env, shape, hint):
+    """Conv2DTranspose(4, 2, 'same') as four 2x2 phase convolutions; hint 16 = register-staged
+    path, 32 = LDS-DMA path without the resident halo, 11/12/15 = halo variants."""
     from oracle import ops_np, ops_torch
     L, lib, dev = env
+    n, h, w, cin, cout = shape
     rng = np.random.default_rng(3)
-    n, h, w, cin, cout = 2, 6, 7, 64, 32
     x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
     k = bf16_round(rng.normal(0, 0.1, (4, 4, cout, cin)))      # Keras layout
     want = ops_np.conv2d_transpose_4x4s2(x, k)
@@ -201,9 +206,10 @@ def test_conv_transpose_4x4s2(env):
     d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin, cin * w, cin * w * h
     d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * 2 * w, cout * 4 * w * h
     d.out_dtype, d.transposed, d.temperature = L.DT_F32, 1, 1.0
+    d.tile_hint = hint
     L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
     torch.cuda.synchronize()
-    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-4)
 
 
 @pytest.mark.parametrize("classes,act", [(3, 2), (4, 2), (1, 3), (2, 2)])
