@@ -171,6 +171,114 @@ int miseg_collapse_u8(const float* probs, uint8_t* out, int64_t pixels, int32_t 
 int miseg_loss_sums(const float* gt, const float* pr, double* sums, int64_t pixels, int32_t C,
                     void* stream);
 
+/* ------------------------------------------------------------------ training ---
+ * The backward half of Model.fit (model_train.py:284-329): the kernels below, with
+ * miseg_conv2d_fwd reused for the data gradients (a data gradient is a convolution of
+ * the output gradient with repacked weights), replace the gradient ops TensorFlow
+ * generates for the same Keras layers.
+ */
+
+/*
+ * Weight gradient of Conv2D (and, per phase, of Conv2DTranspose):
+ *   dw[co][ky][kx][ci] += sum_{n,oy,ox} dy[n,oy,ox,co] *
+ *                         x[n, oy*stride_y - pad_y + ky, ox*stride_x - pad_x + kx, ci]
+ * x, dy: bf16 NHWC views (strides in elements); dw: fp32 [Cout][KH][KW][Cin], accumulated
+ * with float atomics (the caller zeroes it).  Cin % 8 == 0 and Cout % 8 == 0.
+ */
+typedef struct miseg_wgrad_desc {
+  const void* x;
+  const void* dy;
+  float* dw;
+  int32_t N, H, W, Cin;
+  int32_t Ho, Wo, Cout;
+  int32_t KH, KW, stride_y, stride_x, pad_y, pad_x;
+  int32_t x_pix, x_row;
+  int64_t x_img;
+  int32_t dy_pix, dy_row;
+  int64_t dy_img;
+} miseg_wgrad_desc;
+int miseg_conv2d_wgrad(const miseg_wgrad_desc* d, void* stream);
+
+/*
+ * BatchNormalization in training mode, forward statistics.  x: bf16 [pixels][C] view.
+ * Writes the batch mean and biased variance, y = x*scale + shift coefficients
+ * (scale = gamma*rsqrt(var+eps), shift = beta - mean*scale; gamma == NULL means 1), and
+ * updates the moving statistics in place: moving = momentum*moving + (1-momentum)*batch,
+ * with the UNBIASED variance for moving_var (Keras' fused batch norm).
+ * workspace: double[2*C], zeroed by the call.
+ */
+int miseg_bn_stats_fwd(const void* x, int64_t pixels, int32_t C, int32_t pix_stride,
+                       const float* gamma, const float* beta, float* moving_mean,
+                       float* moving_var, float momentum, float eps, float* mean, float* var,
+                       float* scale, float* shift, double* workspace, void* stream);
+/* The same for the fp32 3-channel network input (ResNet `bn_data`, scale=False). */
+int miseg_input_stats_fwd(const float* x, int64_t pixels, const float* beta, float* moving_mean,
+                          float* moving_var, float momentum, float eps, float* mean, float* var,
+                          float* scale, float* shift, double* workspace, void* stream);
+
+/*
+ * Backward of y = relu(x*scale + shift) (BatchNormalization + ReLU, batch statistics).
+ * Pass 1 (reduce): g = dy * [x*scale + shift > 0] (relu == 0: g = dy);
+ *   sums[c] += sum g, sums[C + c] += sum g * xhat, xhat = (x - mean) * rsqrt(var + eps).
+ *   dbeta = sums[0:C], dgamma = sums[C:2C].  sums: double[2*C], zeroed by the call.
+ * Pass 2 (apply): dx = scale * (g - sums[c]/pixels - xhat * sums[C+c]/pixels)   (bf16).
+ */
+int miseg_bn_relu_bwd_reduce(const void* x, const void* dy, int64_t pixels, int32_t C,
+                             int32_t x_pix_stride, int32_t dy_pix_stride, const float* scale,
+                             const float* shift, const float* mean, const float* var, float eps,
+                             int32_t relu, double* sums, void* stream);
+int miseg_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, int64_t pixels, int32_t C,
+                            int32_t x_pix_stride, int32_t dy_pix_stride, int32_t dx_pix_stride,
+                            const float* scale, const float* shift, const float* mean,
+                            const float* var, float eps, int32_t relu, const double* sums,
+                            void* stream);
+
+/* dx of ZeroPadding2D(1)+MaxPooling2D(3,2): the gradient goes to the first maximum of each
+ * window in row-major scan order.  x: pool input [N,H,W,C], dy: [N,H/2,W/2,C], bf16. */
+int miseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+                           int32_t C, int32_t x_pix_stride, int32_t dy_pix_stride,
+                           int32_t dx_pix_stride, void* stream);
+/* dx[n,y,x,c] = dy[n,y/2,x/2,c] / 4.  H, W are the pool INPUT dims. */
+int miseg_avgpool2x2_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t dy_pix_stride, int32_t dx_pix_stride, void* stream);
+/* dx[n,y,x,c] = sum of dy over the 2^shift x 2^shift block it was copied to.  H, W: input dims. */
+int miseg_upsample_nearest_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                               int32_t shift, int32_t dy_pix_stride, int32_t dx_pix_stride,
+                               void* stream);
+/* Transpose of the half-pixel bilinear x2 interpolation.  H, W: input dims. */
+int miseg_upsample_bilinear2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, int32_t dy_pix_stride, int32_t dx_pix_stride,
+                                  void* stream);
+/* out[p][0:C] = in[p][0:C] (+ addend[p][0:C]); bf16 channel-slice copy / accumulate
+ * (Concatenate forward and backward, gradient accumulation at fan-out). */
+int miseg_copy_channels(const void* in, const void* addend, void* out, int64_t pixels, int32_t C,
+                        int32_t in_pix_stride, int32_t add_pix_stride, int32_t out_pix_stride,
+                        void* stream);
+/* per-channel sum of a bf16 [pixels][C] view into double sums[C] (bias gradients); zeroed here. */
+int miseg_channel_sums(const void* x, int64_t pixels, int32_t C, int32_t pix_stride, double* sums,
+                       void* stream);
+
+/*
+ * Gradient of loss_scale * cce_dice_loss (segmentation_models cce_dice_loss, selected at
+ * model_train.py:173) with respect to the LOGITS of the softmax head, per pixel:
+ *   g_c  = d loss / d pr_c  (cross-entropy term masked where clip(pr) saturates; Dice term
+ *          from the per-class sums that miseg_loss_sums produced over the same tensors)
+ *   dz_c = pr_c * (g_c - sum_j g_j pr_j) / temperature
+ * gt, pr: fp32 [pixels][C]; dlogits: bf16 [pixels][out_stride] (channels >= C left untouched).
+ * use_cce / use_dice select the terms.
+ */
+int miseg_loss_grad(const float* gt, const float* pr, const double* sums, void* dlogits,
+                    int64_t pixels, int32_t C, int32_t out_stride, float loss_scale,
+                    float temperature, int32_t use_cce, int32_t use_dice, void* stream);
+
+/*
+ * Keras-form Adam on flat fp32 buffers:  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
+ * p -= lr_t * m / (sqrt(v) + eps),  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (computed by the caller);
+ * grad_scale multiplies g first.  Also writes the bf16 working copy of p when p_bf16 != NULL.
+ */
+int miseg_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t count,
+                    float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
 /*
  * A plan is a recorded list of the calls above with fixed arguments, replayed
  * with one call per forward pass (the analogue of the compiled tf.function

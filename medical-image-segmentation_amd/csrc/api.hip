@@ -31,6 +31,28 @@ int launch_scale_shift_relu(const void*, void*, const float*, const float*, long
                             int, hipStream_t);
 int launch_collapse_u8(const float*, uint8_t*, long long, int, int, hipStream_t);
 int launch_loss_sums(const float*, const float*, double*, long long, int, hipStream_t);
+int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream);
+int launch_bn_stats(const void*, long long, int, int, const float*, const float*, float*, float*, float,
+                    float, float*, float*, float*, float*, double*, hipStream_t);
+int launch_input_stats(const float*, long long, const float*, float*, float*, float, float, float*,
+                       float*, float*, float*, double*, hipStream_t);
+int launch_bn_relu_bwd_reduce(const void*, const void*, long long, int, int, int, const float*,
+                              const float*, const float*, const float*, float, int, double*,
+                              hipStream_t);
+int launch_bn_relu_bwd_apply(const void*, const void*, void*, long long, int, int, int, int,
+                             const float*, const float*, const float*, const float*, float, int,
+                             const double*, hipStream_t);
+int launch_channel_sums(const void*, long long, int, int, double*, hipStream_t);
+int launch_maxpool3x3s2_bwd(const void*, const void*, void*, int, int, int, int, int, int, int,
+                            hipStream_t);
+int launch_avgpool2x2_bwd(const void*, void*, int, int, int, int, int, int, hipStream_t);
+int launch_upsample_nearest_bwd(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int launch_upsample_bilinear2x_bwd(const void*, void*, int, int, int, int, int, int, hipStream_t);
+int launch_copy_channels(const void*, const void*, void*, long long, int, int, int, int, hipStream_t);
+int launch_loss_grad(const float*, const float*, const double*, void*, long long, int, int, float,
+                     float, int, int, hipStream_t);
+int launch_adam(float*, float*, float*, const float*, void*, long long, float, float, float, float,
+                float, hipStream_t);
 
 enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR };
 
@@ -143,6 +165,71 @@ int miseg_loss_sums(const float* gt, const float* pr, double* sums, int64_t pixe
   return launch_loss_sums(gt, pr, sums, pixels, C, (hipStream_t)stream);
 }
 
+// ---- training ----
+int miseg_conv2d_wgrad(const miseg_wgrad_desc* d, void* stream) {
+  return launch_wgrad(d, (hipStream_t)stream);
+}
+int miseg_bn_stats_fwd(const void* x, int64_t pixels, int32_t C, int32_t ps, const float* gamma,
+                       const float* beta, float* mm, float* mv, float momentum, float eps,
+                       float* mean, float* var, float* scale, float* shift, double* ws, void* stream) {
+  return launch_bn_stats(x, pixels, C, ps, gamma, beta, mm, mv, momentum, eps, mean, var, scale,
+                         shift, ws, (hipStream_t)stream);
+}
+int miseg_input_stats_fwd(const float* x, int64_t pixels, const float* beta, float* mm, float* mv,
+                          float momentum, float eps, float* mean, float* var, float* scale,
+                          float* shift, double* ws, void* stream) {
+  return launch_input_stats(x, pixels, beta, mm, mv, momentum, eps, mean, var, scale, shift, ws,
+                            (hipStream_t)stream);
+}
+int miseg_bn_relu_bwd_reduce(const void* x, const void* dy, int64_t pixels, int32_t C, int32_t xps,
+                             int32_t dps, const float* scale, const float* shift, const float* mean,
+                             const float* var, float eps, int32_t relu, double* sums, void* stream) {
+  return launch_bn_relu_bwd_reduce(x, dy, pixels, C, xps, dps, scale, shift, mean, var, eps, relu,
+                                   sums, (hipStream_t)stream);
+}
+int miseg_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, int64_t pixels, int32_t C,
+                            int32_t xps, int32_t dps, int32_t ops, const float* scale,
+                            const float* shift, const float* mean, const float* var, float eps,
+                            int32_t relu, const double* sums, void* stream) {
+  return launch_bn_relu_bwd_apply(x, dy, dx, pixels, C, xps, dps, ops, scale, shift, mean, var, eps,
+                                  relu, sums, (hipStream_t)stream);
+}
+int miseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+                           int32_t C, int32_t xps, int32_t dps, int32_t ops, void* stream) {
+  return launch_maxpool3x3s2_bwd(x, dy, dx, N, H, W, C, xps, dps, ops, (hipStream_t)stream);
+}
+int miseg_avgpool2x2_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t dps, int32_t ops, void* stream) {
+  return launch_avgpool2x2_bwd(dy, dx, N, H, W, C, dps, ops, (hipStream_t)stream);
+}
+int miseg_upsample_nearest_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                               int32_t shift, int32_t dps, int32_t ops, void* stream) {
+  return launch_upsample_nearest_bwd(dy, dx, N, H, W, C, shift, dps, ops, (hipStream_t)stream);
+}
+int miseg_upsample_bilinear2x_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+                                  int32_t C, int32_t dps, int32_t ops, void* stream) {
+  return launch_upsample_bilinear2x_bwd(dy, dx, N, H, W, C, dps, ops, (hipStream_t)stream);
+}
+int miseg_copy_channels(const void* in, const void* addend, void* out, int64_t pixels, int32_t C,
+                        int32_t ips, int32_t aps, int32_t ops, void* stream) {
+  return launch_copy_channels(in, addend, out, pixels, C, ips, aps, ops, (hipStream_t)stream);
+}
+int miseg_channel_sums(const void* x, int64_t pixels, int32_t C, int32_t ps, double* sums,
+                       void* stream) {
+  return launch_channel_sums(x, pixels, C, ps, sums, (hipStream_t)stream);
+}
+int miseg_loss_grad(const float* gt, const float* pr, const double* sums, void* dlogits,
+                    int64_t pixels, int32_t C, int32_t out_stride, float loss_scale,
+                    float temperature, int32_t use_cce, int32_t use_dice, void* stream) {
+  return launch_loss_grad(gt, pr, sums, dlogits, pixels, C, out_stride, loss_scale, temperature,
+                          use_cce, use_dice, (hipStream_t)stream);
+}
+int miseg_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t count,
+                    float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  return launch_adam(p, m, v, g, p_bf16, count, lr_t, beta1, beta2, eps, grad_scale,
+                     (hipStream_t)stream);
+}
+
 // ---- plan ----
 miseg_plan* miseg_plan_create(void) { return new miseg_plan(); }
 void miseg_plan_destroy(miseg_plan* p) { delete p; }
@@ -238,8 +325,8 @@ int miseg_plan_run_range(const miseg_plan* p, int first, int last, void* stream,
     hipError_t e = hipEventRecord(e1, s);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     if (e == hipSuccess) e = hipEventElapsedTime(ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     if (rc == MISEG_OK && e != hipSuccess) {
       set_error("plan timing failed: %s", hipGetErrorString(e));
       rc = MISEG_E_HIP;

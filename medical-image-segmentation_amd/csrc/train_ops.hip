@@ -1,0 +1,631 @@
+// Bandwidth-bound kernels of the training pass on gfx950: BatchNormalization batch
+// statistics and its backward, pooling / upsampling backward, channel-slice copies,
+// the loss gradient at the logits and the Keras-form Adam update.  bf16 tensors are NHWC
+// views with a pixel stride in elements; every thread moves 16 bytes (8 channels) per access.
+#include "common.h"
+
+namespace miseg {
+
+static inline int grid_cap(long long work, int block = 256, int cap = 2048) {
+  long long g = (work + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ void unpack8f(float (&m)[8], const uint4 v) {
+  m[0] = bf16lo_to_f32(v.x); m[1] = bf16hi_to_f32(v.x);
+  m[2] = bf16lo_to_f32(v.y); m[3] = bf16hi_to_f32(v.y);
+  m[4] = bf16lo_to_f32(v.z); m[5] = bf16hi_to_f32(v.z);
+  m[6] = bf16lo_to_f32(v.w); m[7] = bf16hi_to_f32(v.w);
+}
+__device__ __forceinline__ uint4 pack8f(const float (&m)[8]) {
+  return make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]),
+                    pack_bf16x2(m[6], m[7]));
+}
+
+// Work item i = pixel * C8 + c8.  The grid stride is rounded down to a multiple of C8 so a
+// thread keeps one channel group for its whole trip and can accumulate in registers.
+struct ChanWalk {
+  long long first, stride, total;
+  int c8;
+  bool active;
+  __device__ ChanWalk(long long pixels, int C8) {
+    const long long threads = (long long)gridDim.x * blockDim.x;
+    stride = threads / C8 * C8;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    active = gid < stride;
+    first = gid;
+    total = pixels * C8;
+    c8 = (int)(gid % C8);
+  }
+};
+
+// Block-level reduction of per-thread channel partials through LDS double atomics, then
+// one global double atomic per channel and block.
+template <int NACC>
+__device__ __forceinline__ void flush_channel_sums(const float (&acc)[NACC][8], int c8, bool active,
+                                                   int C, double* gsums, double* lsums) {
+  for (int i = threadIdx.x; i < NACC * C; i += blockDim.x) lsums[i] = 0.0;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&lsums[a * C + c8 * 8 + j], (double)acc[a][j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NACC * C; i += blockDim.x)
+    if (lsums[i] != 0.0) atomicAdd(&gsums[i], lsums[i]);
+}
+
+// ------------------------------------------------------------------ BN forward statistics
+__global__ void bn_stats_kernel(const bf16_t* __restrict__ x, long long pixels, int C, int ps,
+                                double* __restrict__ sums) {
+  extern __shared__ double lsums[];
+  const int C8 = C >> 3;
+  ChanWalk w(pixels, C8);
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
+  if (w.active) {
+    for (long long i = w.first; i < w.total; i += w.stride) {
+      const long long pix = i / C8;
+      float v[8];
+      unpack8f(v, *reinterpret_cast<const uint4*>(x + pix * ps + w.c8 * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc[0][j] += v[j];
+        acc[1][j] += v[j] * v[j];
+      }
+    }
+  }
+  flush_channel_sums<2>(acc, w.c8, w.active, C, sums, lsums);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, long long count, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* moving_mean, float* moving_var, float momentum, float eps,
+                                   float* mean, float* var, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = sums[c] / (double)count;
+  double v = sums[C + c] / (double)count - m * m;
+  if (v < 0) v = 0;
+  mean[c] = (float)m;
+  var[c] = (float)v;
+  const float inv = 1.0f / sqrtf((float)v + eps);
+  const float sc = gamma ? gamma[c] * inv : inv;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)m * sc;
+  if (moving_mean) {
+    const double unbiased = count > 1 ? v * (double)count / (double)(count - 1) : v;
+    moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)m;
+    moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unbiased;
+  }
+}
+
+int launch_bn_stats(const void* x, long long pixels, int C, int ps, const float* gamma,
+                    const float* beta, float* mm, float* mv, float momentum, float eps, float* mean,
+                    float* var, float* scale, float* shift, double* ws, hipStream_t s) {
+  MISEG_CHECK_ARG(x && beta && mean && var && scale && shift && ws, "bn_stats: null pointer");
+  MISEG_CHECK_ARG(pixels > 0 && C > 0 && (C & 7) == 0 && (ps & 7) == 0 && ps >= C && C <= 4096,
+                  "bn_stats: C must be a multiple of 8 (<= 4096), stride a multiple of 8");
+  MISEG_CHECK_ARG((mm == nullptr) == (mv == nullptr), "bn_stats: moving stats go together");
+  MISEG_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s));
+  const int grid = grid_cap(pixels * (C >> 3));
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), sizeof(double) * 2 * C, s,
+                     (const bf16_t*)x, pixels, C, ps, ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, pixels, C, gamma,
+                     beta, mm, mv, momentum, eps, mean, var, scale, shift);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// fp32 3-channel network input
+__global__ void input_stats_kernel(const float* __restrict__ x, long long pixels,
+                                   double* __restrict__ sums) {
+  float acc[6] = {0, 0, 0, 0, 0, 0};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pixels;
+       i += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = x[i * 3 + c];
+      acc[c] += v;
+      acc[3 + c] += v * v;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float v = acc[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sums[j], (double)v);
+  }
+}
+
+int launch_input_stats(const float* x, long long pixels, const float* beta, float* mm, float* mv,
+                       float momentum, float eps, float* mean, float* var, float* scale,
+                       float* shift, double* ws, hipStream_t s) {
+  MISEG_CHECK_ARG(x && beta && mean && var && scale && shift && ws, "input_stats: null pointer");
+  MISEG_CHECK_ARG(pixels > 0, "input_stats: no pixels");
+  MISEG_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 6, s));
+  hipLaunchKernelGGL(input_stats_kernel, dim3(grid_cap(pixels)), dim3(256), 0, s, x, pixels, ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, ws, pixels, 3, (const float*)nullptr,
+                     beta, mm, mv, momentum, eps, mean, var, scale, shift);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ------------------------------------------------------------------ BN + ReLU backward
+__global__ void bn_relu_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                          long long pixels, int C, int xps, int dps,
+                                          const float* __restrict__ scale,
+                                          const float* __restrict__ shift,
+                                          const float* __restrict__ mean,
+                                          const float* __restrict__ var, float eps, int relu,
+                                          double* __restrict__ sums) {
+  extern __shared__ double lsums[];
+  const int C8 = C >> 3;
+  ChanWalk w(pixels, C8);
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
+  if (w.active) {
+    float sc[8], sh[8], mu[8], inv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = w.c8 * 8 + j;
+      sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c];
+      inv[j] = 1.0f / sqrtf(var[c] + eps);
+    }
+    for (long long i = w.first; i < w.total; i += w.stride) {
+      const long long pix = i / C8;
+      float xv[8], g[8];
+      unpack8f(xv, *reinterpret_cast<const uint4*>(x + pix * xps + w.c8 * 8));
+      unpack8f(g, *reinterpret_cast<const uint4*>(dy + pix * dps + w.c8 * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gg = (relu && xv[j] * sc[j] + sh[j] <= 0.f) ? 0.f : g[j];
+        acc[0][j] += gg;
+        acc[1][j] += gg * (xv[j] - mu[j]) * inv[j];
+      }
+    }
+  }
+  flush_channel_sums<2>(acc, w.c8, w.active, C, sums, lsums);
+}
+
+__global__ void bn_relu_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                         bf16_t* __restrict__ dx, long long pixels, int C, int xps,
+                                         int dps, int ops, const float* __restrict__ scale,
+                                         const float* __restrict__ shift,
+                                         const float* __restrict__ mean,
+                                         const float* __restrict__ var, float eps, int relu,
+                                         const double* __restrict__ sums) {
+  const int C8 = C >> 3;
+  ChanWalk w(pixels, C8);
+  if (!w.active) return;
+  float sc[8], sh[8], mu[8], inv[8], k1[8], k2[8];
+  const float rcount = 1.0f / (float)pixels;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = w.c8 * 8 + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c];
+    inv[j] = 1.0f / sqrtf(var[c] + eps);
+    k1[j] = (float)sums[c] * rcount;
+    k2[j] = (float)sums[C + c] * rcount;
+  }
+  for (long long i = w.first; i < w.total; i += w.stride) {
+    const long long pix = i / C8;
+    float xv[8], g[8], o[8];
+    unpack8f(xv, *reinterpret_cast<const uint4*>(x + pix * xps + w.c8 * 8));
+    unpack8f(g, *reinterpret_cast<const uint4*>(dy + pix * dps + w.c8 * 8));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gg = (relu && xv[j] * sc[j] + sh[j] <= 0.f) ? 0.f : g[j];
+      const float xhat = (xv[j] - mu[j]) * inv[j];
+      o[j] = sc[j] * (gg - k1[j] - xhat * k2[j]);
+    }
+    *reinterpret_cast<uint4*>(dx + pix * ops + w.c8 * 8) = pack8f(o);
+  }
+}
+
+static int check_bn_bwd(const void* x, const void* dy, long long pixels, int C, int xps, int dps) {
+  MISEG_CHECK_ARG(x && dy, "bn_relu_bwd: null pointer");
+  MISEG_CHECK_ARG(pixels > 0 && C > 0 && (C & 7) == 0 && (xps & 7) == 0 && (dps & 7) == 0 &&
+                      C <= 4096,
+                  "bn_relu_bwd: C must be a multiple of 8 (<= 4096), strides multiples of 8");
+  return MISEG_OK;
+}
+
+int launch_bn_relu_bwd_reduce(const void* x, const void* dy, long long pixels, int C, int xps,
+                              int dps, const float* scale, const float* shift, const float* mean,
+                              const float* var, float eps, int relu, double* sums, hipStream_t s) {
+  int rc = check_bn_bwd(x, dy, pixels, C, xps, dps);
+  if (rc) return rc;
+  MISEG_CHECK_ARG(scale && shift && mean && var && sums, "bn_relu_bwd_reduce: null pointer");
+  MISEG_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s));
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(grid_cap(pixels * (C >> 3))), dim3(256),
+                     sizeof(double) * 2 * C, s, (const bf16_t*)x, (const bf16_t*)dy, pixels, C, xps,
+                     dps, scale, shift, mean, var, eps, relu, sums);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+int launch_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, long long pixels, int C,
+                             int xps, int dps, int ops, const float* scale, const float* shift,
+                             const float* mean, const float* var, float eps, int relu,
+                             const double* sums, hipStream_t s) {
+  int rc = check_bn_bwd(x, dy, pixels, C, xps, dps);
+  if (rc) return rc;
+  MISEG_CHECK_ARG(dx && scale && shift && mean && var && sums && (ops & 7) == 0,
+                  "bn_relu_bwd_apply: null pointer or bad stride");
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(grid_cap(pixels * (C >> 3), 256, 4096)), dim3(256),
+                     0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, pixels, C, xps, dps, ops,
+                     scale, shift, mean, var, eps, relu, sums);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ------------------------------------------------------------------ channel sums (bias grads)
+__global__ void channel_sums_kernel(const bf16_t* __restrict__ x, long long pixels, int C, int ps,
+                                    double* __restrict__ sums) {
+  extern __shared__ double lsums[];
+  const int C8 = C >> 3;
+  ChanWalk w(pixels, C8);
+  float acc[1][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = 0.f;
+  if (w.active) {
+    for (long long i = w.first; i < w.total; i += w.stride) {
+      float v[8];
+      unpack8f(v, *reinterpret_cast<const uint4*>(x + (i / C8) * ps + w.c8 * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[0][j] += v[j];
+    }
+  }
+  flush_channel_sums<1>(acc, w.c8, w.active, C, sums, lsums);
+}
+
+int launch_channel_sums(const void* x, long long pixels, int C, int ps, double* sums, hipStream_t s) {
+  MISEG_CHECK_ARG(x && sums && pixels > 0 && C > 0 && (C & 7) == 0 && (ps & 7) == 0 && C <= 4096,
+                  "channel_sums: bad argument");
+  MISEG_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * C, s));
+  hipLaunchKernelGGL(channel_sums_kernel, dim3(grid_cap(pixels * (C >> 3))), dim3(256),
+                     sizeof(double) * C, s, (const bf16_t*)x, pixels, C, ps, sums);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ------------------------------------------------------------------ pooling / upsampling backward
+__global__ void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                        bf16_t* __restrict__ dx, int N, int H, int W, int C, int xps,
+                                        int dps, int ops) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, C8 = C >> 3;
+  const long long total = (long long)N * H * W * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ix = (int)(r % W);
+    r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    const bf16_t* xb = x + (long long)n * H * W * xps + c8 * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    // windows (oy, ox) that contain (iy, ix): window oy covers rows 2oy-1 .. 2oy+1
+    const int oy_lo = iy / 2, oy_hi = (iy + 1) / 2;       // iy odd: two windows, even: one
+    const int ox_lo = ix / 2, ox_hi = (ix + 1) / 2;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      if (oy >= Ho) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        if (ox >= Wo) continue;
+        // first maximum of the window in row-major order; padded positions hold 0
+        float best[8];
+        int bidx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { best[j] = -3.0e38f; bidx[j] = -1; }
+        for (int dy_ = 0; dy_ < 3; ++dy_) {
+          const int y = 2 * oy - 1 + dy_;
+          for (int dx_ = 0; dx_ < 3; ++dx_) {
+            const int xx = 2 * ox - 1 + dx_;
+            float v[8];
+            if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) {
+              unpack8f(v, *reinterpret_cast<const uint4*>(xb + ((long long)y * W + xx) * xps));
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (v[j] > best[j]) { best[j] = v[j]; bidx[j] = dy_ * 3 + dx_; }
+          }
+        }
+        const int my = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
+        float g[8];
+        unpack8f(g, *reinterpret_cast<const uint4*>(
+                        dy + (((long long)n * Ho + oy) * Wo + ox) * dps + c8 * 8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (bidx[j] == my) acc[j] += g[j];
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + (((long long)n * H + iy) * W + ix) * ops + c8 * 8) = pack8f(acc);
+  }
+}
+
+int launch_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C,
+                            int xps, int dps, int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(x && dy && dx, "maxpool_bwd: null pointer");
+  MISEG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (xps & 7) == 0 &&
+                      (dps & 7) == 0 && (ops & 7) == 0,
+                  "maxpool_bwd: C and strides must be multiples of 8");
+  const long long total = (long long)N * H * W * (C >> 3);
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_cap(total, 256, 8192)), dim3(256), 0, s,
+                     (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, xps, dps, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+__global__ void avgpool2x2_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N,
+                                      int H, int W, int C, int dps, int ops) {
+  const int Ho = H >> 1, Wo = W >> 1, C8 = C >> 3;
+  const long long total = (long long)N * H * W * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ix = (int)(r % W);
+    r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    float g[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((iy >> 1) < Ho && (ix >> 1) < Wo) {
+      unpack8f(g, *reinterpret_cast<const uint4*>(
+                      dy + (((long long)n * Ho + (iy >> 1)) * Wo + (ix >> 1)) * dps + c8 * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] *= 0.25f;
+    }
+    *reinterpret_cast<uint4*>(dx + (((long long)n * H + iy) * W + ix) * ops + c8 * 8) = pack8f(g);
+  }
+}
+
+int launch_avgpool2x2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dps, int ops,
+                          hipStream_t s) {
+  MISEG_CHECK_ARG(dy && dx && N > 0 && H > 1 && W > 1 && C > 0 && (C & 7) == 0 && (dps & 7) == 0 &&
+                      (ops & 7) == 0,
+                  "avgpool_bwd: bad argument");
+  const long long total = (long long)N * H * W * (C >> 3);
+  hipLaunchKernelGGL(avgpool2x2_bwd_kernel, dim3(grid_cap(total, 256, 8192)), dim3(256), 0, s,
+                     (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, dps, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+__global__ void upsample_nearest_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                            int N, int H, int W, int C, int shift, int dps, int ops) {
+  const int s = 1 << shift, Wo = W << shift, Ho = H << shift, C8 = C >> 3;
+  const long long total = (long long)N * H * W * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ix = (int)(r % W);
+    r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < s; ++a)
+      for (int b = 0; b < s; ++b) {
+        float g[8];
+        unpack8f(g, *reinterpret_cast<const uint4*>(
+                        dy + (((long long)n * Ho + (iy * s + a)) * Wo + (ix * s + b)) * dps + c8 * 8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += g[j];
+      }
+    *reinterpret_cast<uint4*>(dx + (((long long)n * H + iy) * W + ix) * ops + c8 * 8) = pack8f(acc);
+  }
+}
+
+int launch_upsample_nearest_bwd(const void* dy, void* dx, int N, int H, int W, int C, int shift,
+                                int dps, int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (dps & 7) == 0 &&
+                      (ops & 7) == 0 && shift >= 0 && shift <= 4,
+                  "upsample_nearest_bwd: bad argument");
+  const long long total = (long long)N * H * W * (C >> 3);
+  hipLaunchKernelGGL(upsample_nearest_bwd_kernel, dim3(grid_cap(total, 256, 8192)), dim3(256), 0, s,
+                     (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, shift, dps, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// forward coefficients of the x2 half-pixel bilinear resize along one axis
+__device__ __forceinline__ void bil_coef(int o, int n, int& i0, int& i1, float& f) {
+  float s = fminf(fmaxf((o + 0.5f) * 0.5f - 0.5f, 0.f), (float)(n - 1));
+  i0 = (int)s;
+  i1 = min(i0 + 1, n - 1);
+  f = s - i0;
+}
+
+__global__ void upsample_bilinear2x_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx,
+                                               int N, int H, int W, int C, int dps, int ops) {
+  const int Ho = 2 * H, Wo = 2 * W, C8 = C >> 3;
+  const long long total = (long long)N * H * W * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ix = (int)(r % W);
+    r /= W;
+    const int iy = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int oy = 2 * iy - 1; oy <= 2 * iy + 2; ++oy) {
+      if ((unsigned)oy >= (unsigned)Ho) continue;
+      int y0, y1;
+      float fy;
+      bil_coef(oy, H, y0, y1, fy);
+      const float wy = (y0 == iy ? 1.f - fy : 0.f) + (y1 == iy ? fy : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = 2 * ix - 1; ox <= 2 * ix + 2; ++ox) {
+        if ((unsigned)ox >= (unsigned)Wo) continue;
+        int x0, x1;
+        float fx;
+        bil_coef(ox, W, x0, x1, fx);
+        const float wx = (x0 == ix ? 1.f - fx : 0.f) + (x1 == ix ? fx : 0.f);
+        if (wx == 0.f) continue;
+        float g[8];
+        unpack8f(g, *reinterpret_cast<const uint4*>(
+                        dy + (((long long)n * Ho + oy) * Wo + ox) * dps + c8 * 8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy * wx * g[j];
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + (((long long)n * H + iy) * W + ix) * ops + c8 * 8) = pack8f(acc);
+  }
+}
+
+int launch_upsample_bilinear2x_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dps,
+                                   int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (dps & 7) == 0 &&
+                      (ops & 7) == 0,
+                  "upsample_bilinear2x_bwd: bad argument");
+  const long long total = (long long)N * H * W * (C >> 3);
+  hipLaunchKernelGGL(upsample_bilinear2x_bwd_kernel, dim3(grid_cap(total, 256, 8192)), dim3(256), 0, s,
+                     (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, dps, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ------------------------------------------------------------------ channel-slice copy / add
+__global__ void copy_channels_kernel(const bf16_t* __restrict__ in, const bf16_t* __restrict__ add,
+                                     bf16_t* __restrict__ out, long long pixels, int C, int ips,
+                                     int aps, int ops) {
+  const int C8 = C >> 3;
+  const long long total = pixels * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    const long long pix = i / C8;
+    uint4 v = *reinterpret_cast<const uint4*>(in + pix * ips + c8 * 8);
+    if (add) {
+      float a[8], b[8];
+      unpack8f(a, v);
+      unpack8f(b, *reinterpret_cast<const uint4*>(add + pix * aps + c8 * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += b[j];
+      v = pack8f(a);
+    }
+    *reinterpret_cast<uint4*>(out + pix * ops + c8 * 8) = v;
+  }
+}
+
+int launch_copy_channels(const void* in, const void* add, void* out, long long pixels, int C, int ips,
+                         int aps, int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(in && out && pixels > 0 && C > 0 && (C & 7) == 0 && (ips & 7) == 0 &&
+                      (ops & 7) == 0 && (!add || (aps & 7) == 0),
+                  "copy_channels: bad argument");
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_cap(pixels * (C >> 3), 256, 8192)), dim3(256), 0,
+                     s, (const bf16_t*)in, (const bf16_t*)add, (bf16_t*)out, pixels, C, ips, aps, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ------------------------------------------------------------------ loss gradient at the logits
+template <int C>
+__global__ void loss_grad_kernel(const float* __restrict__ gt, const float* __restrict__ pr,
+                                 const double* __restrict__ sums, bf16_t* __restrict__ dz,
+                                 long long pixels, int out_stride, float loss_scale,
+                                 float inv_temperature, int use_cce, int use_dice) {
+  // Dice: score_c = (2 tp_c + s) / (sum gt_c + sum pr_c + s);  d(1 - mean score)/d pr_{p,c}
+  //       = -(2 gt_{p,c} den_c - num_c) / den_c^2 / C
+  float dnum[C], dden[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const double num = 2.0 * sums[c] + 1e-5;
+    const double den = sums[C + c] + sums[2 * C + c] + 1e-5;
+    dnum[c] = (float)(num / (den * den) / C);
+    dden[c] = (float)(2.0 / den / C);
+  }
+  const float cce_w = 1.0f / ((float)pixels * C);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pixels;
+       i += (long long)gridDim.x * blockDim.x) {
+    float g[C], p[C], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      p[c] = pr[i * C + c];
+      s += p[c];
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float t = gt[i * C + c];
+      float gc = 0.f;
+      if (use_cce) {
+        const float q = p[c] / s;
+        if (q > 1e-7f && q < 1.f - 1e-7f) gc += -t * cce_w / p[c];
+      }
+      if (use_dice) gc += dnum[c] - t * dden[c];
+      g[c] = gc * loss_scale;
+      dot += g[c] * p[c];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      dz[i * out_stride + c] = f32_to_bf16(p[c] * (g[c] - dot) * inv_temperature);
+  }
+}
+
+int launch_loss_grad(const float* gt, const float* pr, const double* sums, void* dz, long long pixels,
+                     int C, int out_stride, float loss_scale, float temperature, int use_cce,
+                     int use_dice, hipStream_t s) {
+  MISEG_CHECK_ARG(gt && pr && sums && dz, "loss_grad: null pointer");
+  MISEG_CHECK_ARG(pixels > 0 && C >= 2 && C <= 8 && out_stride >= C && temperature > 0.f,
+                  "loss_grad: need 2 <= C <= 8, out_stride >= C, temperature > 0");
+  const dim3 grid(grid_cap(pixels, 256, 4096)), block(256);
+  const float it = 1.f / temperature;
+  bf16_t* o = (bf16_t*)dz;
+#define MISEG_LG(CC)                                                                             \
+  case CC:                                                                                       \
+    hipLaunchKernelGGL(loss_grad_kernel<CC>, grid, block, 0, s, gt, pr, sums, o, pixels,         \
+                       out_stride, loss_scale, it, use_cce, use_dice);                           \
+    break;
+  switch (C) {
+    MISEG_LG(2) MISEG_LG(3) MISEG_LG(4) MISEG_LG(5) MISEG_LG(6) MISEG_LG(7)
+    default:
+      hipLaunchKernelGGL(loss_grad_kernel<8>, grid, block, 0, s, gt, pr, sums, o, pixels, out_stride,
+                         loss_scale, it, use_cce, use_dice);
+  }
+#undef MISEG_LG
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ------------------------------------------------------------------ Adam (Keras form)
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ g, bf16_t* __restrict__ pb, long long count,
+                            float lr_t, float b1, float b2, float eps, float gscale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float pi = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi;
+    if (pb) pb[i] = f32_to_bf16(pi);
+  }
+}
+
+int launch_adam(float* p, float* m, float* v, const float* g, void* pb, long long count, float lr_t,
+                float b1, float b2, float eps, float gscale, hipStream_t s) {
+  MISEG_CHECK_ARG(p && m && v && g && count > 0, "adam: bad argument");
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_cap(count, 256, 4096)), dim3(256), 0, s, p, m, v, g,
+                     (bf16_t*)pb, count, lr_t, b1, b2, eps, gscale);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+}  // namespace miseg

@@ -1,0 +1,263 @@
+// Weight gradient of a convolution on gfx950 (the backward-filter pass that tf.keras runs
+// inside Model.fit, /root/reference model_train.py:284-329, for every Conv2D /
+// Conv2DTranspose the networks of utils/model.py:176-211 contain).
+//
+//   dW[co][tap][ci] = sum over output pixels p of  dY[p][co] * X[p shifted by tap][ci]
+//
+// GEMM view per tap: D[co][ci] = sum_k A[co][k] B[k][ci] with k = output pixel.  Both
+// operands live in memory pixel-major (NHWC), i.e. k is the slow index, so the MFMA
+// fragments (8 consecutive k per lane) are columns of the staged [pixel][channel] LDS
+// tiles: they are fetched with ds_read_b64_tr_b16, the transposing LDS read.
+//
+// Block = 4 waves computing a [BC couts] x [BC cins] tile of one tap over a slice of the
+// pixels (split-K); K-step = 64 pixels; tiles are staged by LDS-DMA, double buffered, with
+// the 16-byte chunk index XOR-swizzled on the source side.  Partial tiles are added to the
+// fp32 gradient with float atomics (two 128-byte row segments per wave instruction).
+#include "common.h"
+
+namespace miseg {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// 16-byte source of LDS-DMA loads for rows that fall outside the tensors
+__device__ __attribute__((aligned(128))) unsigned char g_zero_line_wg[128];
+
+struct WgradParams {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* dw;
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int KH, KW, stride_y, stride_x, pad_y, pad_x;
+  int x_pix, x_row;
+  long long x_img;
+  int dy_pix, dy_row;
+  long long dy_img;
+  int M, ksteps_total, ksplit, ksteps_per_split;
+  int co_tiles, ci_tiles, taps;
+};
+
+template <int BC>
+__device__ __forceinline__ int wg_swz(int row, int chunk) {
+  // BC = 128: 16 chunks per 256-B row; BC = 64: 8 chunks per 128-B row (two rows per bank row)
+  return BC == 128 ? (chunk ^ ((row & 3) << 2)) : (chunk ^ (((row >> 1) & 1) << 2));
+}
+
+template <int BC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  constexpr int RB = BC * 2;              // bytes per LDS row (one pixel)
+  constexpr int RPI = 1024 / RB;          // rows per wave-instruction
+  constexpr int LPR = 64 / RPI;           // lanes per row = 16-byte chunks per row
+  constexpr int NI = 64 / RPI / 4;        // wave-instructions per wave per operand tile
+  constexpr int WT = BC / 64;             // 32x32 MFMA tiles per wave per dimension
+  constexpr int TILE = 64 * RB;           // bytes of one operand tile
+  constexpr int STAGE = 2 * TILE;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  int item = blockIdx.x;
+  const int ci_t = item % p.ci_tiles;
+  item /= p.ci_tiles;
+  const int co_t = item % p.co_tiles;
+  item /= p.co_tiles;
+  const int tap = item % p.taps;
+  const int kz = item / p.taps;
+  const int ky = tap / p.KW, kx = tap - ky * p.KW;
+  const int co0 = co_t * BC, ci0 = ci_t * BC;
+  const int ks_begin = kz * p.ksteps_per_split;
+  int ks_end = ks_begin + p.ksteps_per_split;
+  if (ks_end > p.ksteps_total) ks_end = p.ksteps_total;
+
+  const int HoWo = p.Ho * p.Wo;
+  const int lrow = lane / LPR;            // row within the wave-instruction
+  const int slot = lane % LPR;            // LDS chunk position within the row
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line_wg);
+
+  // per staged row: output pixel coordinates (advanced by 64 pixels per K-step)
+  int r_n[NI], r_oy[NI], r_ox[NI], r_m[NI], r_ch[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int row = (j * 4 + wave) * RPI + lrow;
+    const int m = ks_begin * 64 + row;
+    r_m[j] = m;
+    const int mm = m < p.M ? m : 0;
+    r_n[j] = mm / HoWo;
+    const int rem = mm - r_n[j] * HoWo;
+    r_oy[j] = rem / p.Wo;
+    r_ox[j] = rem - r_oy[j] * p.Wo;
+    r_ch[j] = wg_swz<BC>(row, slot) * 8;   // source channel offset that lands in this slot
+  }
+
+  auto issue = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const bool in_range = r_m[j] < p.M;
+      // dY tile: [pixel][co0 + ...]
+      {
+        const int c = co0 + r_ch[j];
+        const bf16_t* src = (in_range && c < p.Cout)
+                                ? p.dy + r_n[j] * p.dy_img + (long long)r_oy[j] * p.dy_row +
+                                      (long long)r_ox[j] * p.dy_pix + c
+                                : zero_src;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)src,
+            (__attribute__((address_space(3))) void*)(lds + buf * STAGE + (j * 4 + wave) * 1024),
+            16, 0, 0);
+      }
+      // X tile for this tap: [pixel shifted by the tap][ci0 + ...]
+      {
+        const int iy = r_oy[j] * p.stride_y - p.pad_y + ky;
+        const int ix = r_ox[j] * p.stride_x - p.pad_x + kx;
+        const int c = ci0 + r_ch[j];
+        const bool ok = in_range && c < p.Cin && (unsigned)iy < (unsigned)p.H &&
+                        (unsigned)ix < (unsigned)p.W;
+        const bf16_t* src = ok ? p.x + r_n[j] * p.x_img + (long long)iy * p.x_row +
+                                     (long long)ix * p.x_pix + c
+                               : zero_src;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)src,
+            (__attribute__((address_space(3))) void*)(lds + buf * STAGE + TILE +
+                                                      (j * 4 + wave) * 1024),
+            16, 0, 0);
+      }
+      // advance this row by 64 pixels
+      r_m[j] += 64;
+      r_ox[j] += 64;
+      while (r_ox[j] >= p.Wo) {
+        r_ox[j] -= p.Wo;
+        if (++r_oy[j] == p.Ho) {
+          r_oy[j] = 0;
+          ++r_n[j];
+        }
+      }
+    }
+  };
+
+  f32x16 acc[WT][WT];
+#pragma unroll
+  for (int a = 0; a < WT; ++a)
+#pragma unroll
+    for (int b = 0; b < WT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // transposing-read geometry: 16-lane group g reads a 4(k) x 16(channel) block; lane 4q+p of
+  // the group addresses row q, channels 4p..4p+3; lane i of the group receives channel i.
+  const int g = lane >> 4;
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  const int kgrp = 8 * (g >> 1) + tq;      // k row inside a 16-deep sub-step (first read)
+  const int cgrp = 16 * (g & 1) + 4 * tp;  // channel inside the 32-wide MFMA tile
+
+  auto frag = [&](const unsigned char* tile, int krow0, int col0) __attribute__((always_inline)) {
+    // 8 consecutive k (pixels) of one channel column: two transposed 4x16 reads
+    const int col = col0 + cgrp;
+    const int chunk = col >> 3, within = (col & 7) * 2;
+    const int r0 = krow0 + kgrp, r1 = r0 + 4;
+    const unsigned char* a0 = tile + r0 * RB + wg_swz<BC>(r0, chunk) * 16 + within;
+    const unsigned char* a1 = tile + r1 * RB + wg_swz<BC>(r1, chunk) * 16 + within;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4*)(a1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const unsigned char* dyt = lds + buf * STAGE;
+    const unsigned char* xt = dyt + TILE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 af[WT], bfr[WT];
+#pragma unroll
+      for (int a = 0; a < WT; ++a) af[a] = frag(dyt, ks * 16, wm * (WT * 32) + a * 32);
+#pragma unroll
+      for (int b = 0; b < WT; ++b) bfr[b] = frag(xt, ks * 16, wn * (WT * 32) + b * 32);
+#pragma unroll
+      for (int a = 0; a < WT; ++a)
+#pragma unroll
+        for (int b = 0; b < WT; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  };
+
+  if (ks_begin < ks_end) {
+    issue(0);
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+      const int it = ks - ks_begin;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (ks + 1 < ks_end) issue((it + 1) & 1);
+      compute(it & 1);
+    }
+  }
+
+  // accumulate the tile: lane column = ci, register row = co
+  const int lcol = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < WT; ++a)
+#pragma unroll
+    for (int b = 0; b < WT; ++b) {
+      const int ci = ci0 + wn * (WT * 32) + b * 32 + lcol;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * (WT * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+        if (co < p.Cout && ci < p.Cin)
+          atomicAdd(p.dw + ((long long)co * p.taps + tap) * p.Cin + ci, acc[a][b][r]);
+      }
+    }
+}
+
+int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream) {
+  MISEG_CHECK_ARG(d && d->x && d->dy && d->dw, "wgrad: null pointer");
+  MISEG_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cin > 0 &&
+                      d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride_y > 0 && d->stride_x > 0,
+                  "wgrad: non-positive dimension");
+  MISEG_CHECK_ARG((d->Cin & 7) == 0 && (d->Cout & 7) == 0,
+                  "wgrad: Cin and Cout must be multiples of 8 (pad the tensors)");
+  MISEG_CHECK_ARG((d->x_pix & 7) == 0 && (d->x_row & 7) == 0 && (d->x_img & 7) == 0 &&
+                      (d->dy_pix & 7) == 0 && (d->dy_row & 7) == 0 && (d->dy_img & 7) == 0 &&
+                      ((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->dy & 15) == 0,
+                  "wgrad: strides must be multiples of 8 elements, pointers 16-byte aligned");
+  const long long M = (long long)d->N * d->Ho * d->Wo;
+  if (M >= (1ll << 31)) {
+    set_error("wgrad: N*Ho*Wo=%lld exceeds 2^31", M);
+    return MISEG_E_UNSUPPORTED_SHAPE;
+  }
+  WgradParams p;
+  p.x = (const bf16_t*)d->x; p.dy = (const bf16_t*)d->dy; p.dw = d->dw;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.KH = d->KH; p.KW = d->KW; p.stride_y = d->stride_y; p.stride_x = d->stride_x;
+  p.pad_y = d->pad_y; p.pad_x = d->pad_x;
+  p.x_pix = d->x_pix; p.x_row = d->x_row; p.x_img = d->x_img;
+  p.dy_pix = d->dy_pix; p.dy_row = d->dy_row; p.dy_img = d->dy_img;
+  p.M = (int)M;
+  p.ksteps_total = (p.M + 63) / 64;
+  p.taps = d->KH * d->KW;
+  const bool big = d->Cin > 64 && d->Cout > 64;
+  const int bc = big ? 128 : 64;
+  p.co_tiles = (d->Cout + bc - 1) / bc;
+  p.ci_tiles = (d->Cin + bc - 1) / bc;
+  const long long base = (long long)p.co_tiles * p.ci_tiles * p.taps;
+  long long want = (2048 + base - 1) / base;       // aim at ~8 blocks per CU in total
+  if (want > p.ksteps_total) want = p.ksteps_total;
+  if (want < 1) want = 1;
+  p.ksteps_per_split = (int)((p.ksteps_total + want - 1) / want);
+  p.ksplit = (p.ksteps_total + p.ksteps_per_split - 1) / p.ksteps_per_split;
+  const dim3 grid((unsigned)(base * p.ksplit));
+  if (big)
+    hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, stream, p);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+}  // namespace miseg

@@ -40,6 +40,19 @@ class ConvDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    """Mirror of `miseg_wgrad_desc`."""
+    _fields_ = [
+        ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride_y", C.c_int32), ("stride_x", C.c_int32),
+        ("pad_y", C.c_int32), ("pad_x", C.c_int32),
+        ("x_pix", C.c_int32), ("x_row", C.c_int32), ("x_img", C.c_int64),
+        ("dy_pix", C.c_int32), ("dy_row", C.c_int32), ("dy_img", C.c_int64),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/miseg.h declares
 _VP, _I32, _I64, _FP = C.c_void_p, C.c_int32, C.c_int64, C.c_void_p
 SIGNATURES = {
@@ -55,6 +68,25 @@ SIGNATURES = {
     "miseg_scale_shift_relu_fwd": (C.c_int, [_VP, _VP, _FP, _FP, _I64, _I32, _I32, _I32, _VP]),
     "miseg_collapse_u8": (C.c_int, [_FP, _VP, _I64, _I32, _I32, _VP]),
     "miseg_loss_sums": (C.c_int, [_FP, _FP, _VP, _I64, _I32, _VP]),
+    "miseg_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), _VP]),
+    "miseg_bn_stats_fwd": (C.c_int, [_VP, _I64, _I32, _I32, _FP, _FP, _FP, _FP, C.c_float, C.c_float,
+                                     _FP, _FP, _FP, _FP, _VP, _VP]),
+    "miseg_input_stats_fwd": (C.c_int, [_FP, _I64, _FP, _FP, _FP, C.c_float, C.c_float, _FP, _FP, _FP,
+                                        _FP, _VP, _VP]),
+    "miseg_bn_relu_bwd_reduce": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, _FP, _FP, _FP, _FP,
+                                           C.c_float, _I32, _VP, _VP]),
+    "miseg_bn_relu_bwd_apply": (C.c_int, [_VP, _VP, _VP, _I64, _I32, _I32, _I32, _I32, _FP, _FP, _FP,
+                                          _FP, C.c_float, _I32, _VP, _VP]),
+    "miseg_maxpool3x3s2_bwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_avgpool2x2_bwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_upsample_nearest_bwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_upsample_bilinear2x_bwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_copy_channels": (C.c_int, [_VP, _VP, _VP, _I64, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_channel_sums": (C.c_int, [_VP, _I64, _I32, _I32, _VP, _VP]),
+    "miseg_loss_grad": (C.c_int, [_FP, _FP, _VP, _VP, _I64, _I32, _I32, C.c_float, C.c_float, _I32,
+                                  _I32, _VP]),
+    "miseg_adam_step": (C.c_int, [_FP, _FP, _FP, _FP, _VP, _I64, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_float, _VP]),
     "miseg_plan_create": (_VP, []),
     "miseg_plan_destroy": (None, [_VP]),
     "miseg_plan_num_ops": (C.c_int, [_VP]),

@@ -1,0 +1,281 @@
+"""Parity of the training-pass HIP kernels (through the C ABI) against torch-CPU autograd
+and closed-form numpy on seeded inputs rounded to bf16.  Tolerances: fp32-accumulated
+reductions 1e-4 relative; tensors stored in bf16 one bf16 ulp (2^-8 relative)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).float().numpy()
+
+
+@pytest.fixture(scope="module")
+def env():
+    import miseg_amd
+    from miseg_amd import lib as L
+    lib = L.load()
+    L.check(lib.miseg_device_check())
+    return L, lib, torch.device("cuda:0")
+
+
+def dbf(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(dev)
+
+
+def df32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+
+
+WG_CASES = [
+    # n, h, w, cin, cout, k, stride, pad
+    (2, 9, 13, 64, 64, 3, 1, 1),
+    (1, 16, 24, 128, 256, 3, 1, 1),
+    (1, 16, 24, 64, 128, 3, 2, 1),
+    (2, 10, 14, 32, 64, 1, 2, 0),
+    (1, 12, 12, 160, 96, 1, 1, 0),
+    (1, 20, 12, 32, 8, 3, 1, 1),
+    (3, 8, 8, 256, 128, 4, 2, 1),     # the strided 4x4 conv that is the data gradient of a transpose-conv
+    (1, 70, 70, 64, 32, 3, 1, 1),     # several K-steps per split, rows wrapping inside a K-step
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_wgrad(env, case):
+    L, lib, dev = env
+    n, h, w, cin, cout, k, stride, pad = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    dy = bf16_round(rng.normal(0, 1, (n, ho, wo, cout)))
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    wt = torch.zeros((cout, cin, k, k), requires_grad=True)
+    out = F.conv2d(xt, wt, stride=stride, padding=pad)
+    out.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    want = wt.grad.permute(0, 2, 3, 1).numpy()          # [Cout][KH][KW][Cin]
+    xd, dyd = dbf(x, dev), dbf(dy, dev)
+    dw = torch.zeros((cout, k, k, cin), dtype=torch.float32, device=dev)
+    d = L.WgradDesc()
+    d.x, d.dy, d.dw = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, ho, wo, cout
+    d.KH = d.KW = k
+    d.stride_y = d.stride_x = stride
+    d.pad_y = d.pad_x = pad
+    d.x_pix, d.x_row, d.x_img = cin, cin * w, cin * w * h
+    d.dy_pix, d.dy_row, d.dy_img = cout, cout * wo, cout * wo * ho
+    L.check(lib.miseg_conv2d_wgrad(C.byref(d), None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
+def test_wgrad_transpose_conv_phase_views(env):
+    """Weight gradient of Conv2DTranspose(4,2,'same'): one call per phase with dy viewed on the
+    phase's lattice of the output gradient; result in the forward phase layout."""
+    L, lib, dev = env
+    rng = np.random.default_rng(5)
+    n, h, w, cin, cout = 2, 6, 7, 64, 32
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    dout = bf16_round(rng.normal(0, 1, (n, 2 * h, 2 * w, cout)))
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    wt = torch.zeros((cin, cout, 4, 4), requires_grad=True)
+    F.conv_transpose2d(xt, wt, stride=2, padding=1).backward(torch.from_numpy(dout).permute(0, 3, 1, 2))
+    gk = wt.grad.permute(2, 3, 1, 0).numpy()             # Keras (kh, kw, Cout, Cin)
+    xd, dd = dbf(x, dev), dbf(dout, dev)
+    dw = torch.zeros((2, 2, cout, 2, 2, cin), dtype=torch.float32, device=dev)
+    for a in range(2):
+        for b in range(2):
+            d = L.WgradDesc()
+            d.x = xd.data_ptr()
+            d.dy = dd.data_ptr() + 2 * (a * 2 * w * cout + b * cout)
+            d.dw = dw[a, b].data_ptr()
+            d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, h, w, cout
+            d.KH = d.KW = 2
+            d.stride_y = d.stride_x = 1
+            d.pad_y, d.pad_x = 1 - a, 1 - b
+            d.x_pix, d.x_row, d.x_img = cin, cin * w, cin * w * h
+            d.dy_pix, d.dy_row, d.dy_img = 2 * cout, 2 * (2 * w * cout), 4 * h * w * cout
+            L.check(lib.miseg_conv2d_wgrad(C.byref(d), None))
+    torch.cuda.synchronize()
+    got = dw.cpu().numpy()
+    for a in range(2):
+        for b in range(2):
+            for dy_ in range(2):
+                for dx_ in range(2):
+                    np.testing.assert_allclose(got[a, b, :, dy_, dx_, :], gk[3 - a - 2 * dy_, 3 - b - 2 * dx_],
+                                               rtol=1e-4, atol=1e-3)
+
+
+def test_bn_stats_and_backward(env):
+    L, lib, dev = env
+    rng = np.random.default_rng(1)
+    n, h, w, c, extra = 2, 11, 13, 40, 8
+    pixels = n * h * w
+    x = bf16_round(rng.normal(0.3, 1.5, (n, h, w, c)))
+    gamma = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    beta = rng.normal(0, 0.5, c).astype(np.float32)
+    mm0 = rng.normal(0, 1, c).astype(np.float32)
+    mv0 = rng.uniform(0.5, 2, c).astype(np.float32)
+    eps, mom = 1e-3, 0.99
+    xbuf = torch.zeros((n, h, w, c + extra), dtype=torch.bfloat16, device=dev)
+    xbuf[..., extra:] = dbf(x, dev)
+    xptr = xbuf.data_ptr() + 2 * extra
+    g, b_, mm, mv = df32(gamma, dev), df32(beta, dev), df32(mm0, dev), df32(mv0, dev)
+    mean, var, scale, shift = (torch.zeros(c, device=dev) for _ in range(4))
+    ws = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+    L.check(lib.miseg_bn_stats_fwd(xptr, pixels, c, c + extra, g.data_ptr(), b_.data_ptr(), mm.data_ptr(),
+                                   mv.data_ptr(), mom, eps, mean.data_ptr(), var.data_ptr(),
+                                   scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), None))
+    x2 = x.reshape(-1, c).astype(np.float64)
+    m_ref, v_ref = x2.mean(0), x2.var(0)
+    np.testing.assert_allclose(mean.cpu().numpy(), m_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(var.cpu().numpy(), v_ref, rtol=1e-5)
+    sc_ref = gamma / np.sqrt(v_ref + eps)
+    np.testing.assert_allclose(scale.cpu().numpy(), sc_ref, rtol=1e-5)
+    np.testing.assert_allclose(shift.cpu().numpy(), beta - m_ref * sc_ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(mm.cpu().numpy(), mom * mm0 + (1 - mom) * m_ref, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mv.cpu().numpy(), mom * mv0 + (1 - mom) * v_ref * pixels / (pixels - 1), rtol=1e-5)
+    # backward of relu(bn(x)) against torch autograd (batch statistics)
+    dy = bf16_round(rng.normal(0, 1, (n, h, w, c)))
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gt_, bt_ = torch.from_numpy(gamma).requires_grad_(True), torch.from_numpy(beta).requires_grad_(True)
+    y = F.relu(F.batch_norm(xt, None, None, gt_, bt_, True, 0.0, eps))
+    y.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    dyd = dbf(dy, dev)
+    sums = torch.zeros(2 * c, dtype=torch.float64, device=dev)
+    L.check(lib.miseg_bn_relu_bwd_reduce(xptr, dyd.data_ptr(), pixels, c, c + extra, c, scale.data_ptr(),
+                                         shift.data_ptr(), mean.data_ptr(), var.data_ptr(), eps, 1,
+                                         sums.data_ptr(), None))
+    dx = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_bn_relu_bwd_apply(xptr, dyd.data_ptr(), dx.data_ptr(), pixels, c, c + extra, c, c,
+                                        scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                        eps, 1, sums.data_ptr(), None))
+    torch.cuda.synchronize()
+    s = sums.cpu().numpy()
+    np.testing.assert_allclose(s[:c], bt_.grad.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[c:], gt_.grad.numpy(), rtol=1e-4, atol=1e-3)
+    want_dx = xt.grad.permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(dx.float().cpu().numpy(), want_dx, rtol=2e-2, atol=2e-3)
+
+
+def test_input_stats(env):
+    L, lib, dev = env
+    rng = np.random.default_rng(2)
+    x = rng.uniform(0, 1, (2, 16, 20, 3)).astype(np.float32)
+    beta = rng.normal(0, 0.1, 3).astype(np.float32)
+    xd, b_ = df32(x, dev), df32(beta, dev)
+    mm, mv = torch.zeros(3, device=dev), torch.ones(3, device=dev)
+    mean, var, scale, shift = (torch.zeros(3, device=dev) for _ in range(4))
+    ws = torch.zeros(6, dtype=torch.float64, device=dev)
+    L.check(lib.miseg_input_stats_fwd(xd.data_ptr(), 2 * 16 * 20, b_.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+                                      0.99, 2e-5, mean.data_ptr(), var.data_ptr(), scale.data_ptr(),
+                                      shift.data_ptr(), ws.data_ptr(), None))
+    x2 = x.reshape(-1, 3).astype(np.float64)
+    np.testing.assert_allclose(mean.cpu().numpy(), x2.mean(0), rtol=1e-5)
+    np.testing.assert_allclose(scale.cpu().numpy(), 1 / np.sqrt(x2.var(0) + 2e-5), rtol=1e-5)
+    np.testing.assert_allclose(shift.cpu().numpy(), beta - x2.mean(0) / np.sqrt(x2.var(0) + 2e-5), rtol=1e-4, atol=1e-5)
+
+
+def test_pool_and_upsample_backward(env):
+    L, lib, dev = env
+    rng = np.random.default_rng(3)
+    n, h, w, c = 2, 12, 20, 16
+    # max pool: many exact ties at zero, as after a ReLU
+    x = bf16_round(np.maximum(rng.normal(0, 1, (n, h, w, c)), 0))
+    dy = bf16_round(rng.normal(0, 1, (n, h // 2, w // 2, c)))
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    xp = F.pad(xt, (1, 1, 1, 1))
+    F.max_pool2d(xp, 3, 2).backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    xd, dyd = dbf(x, dev), dbf(dy, dev)
+    dx = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_maxpool3x3s2_bwd(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), n, h, w, c, c, c, c, None))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-2, atol=1e-2)
+    # average pool
+    L.check(lib.miseg_avgpool2x2_bwd(dyd.data_ptr(), dx.data_ptr(), n, h, w, c, c, c, None))
+    want = np.repeat(np.repeat(dy, 2, 1), 2, 2) / 4
+    np.testing.assert_array_equal(dx.float().cpu().numpy(), bf16_round(want))
+    # nearest upsample x4
+    g4 = bf16_round(rng.normal(0, 1, (n, 4 * h, 4 * w, c)))
+    L.check(lib.miseg_upsample_nearest_bwd(dbf(g4, dev).data_ptr(), dx.data_ptr(), n, h, w, c, 2, c, c, None))
+    want = g4.reshape(n, h, 4, w, 4, c).sum(axis=(2, 4))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), want, rtol=1e-2, atol=2e-2)
+    # bilinear x2
+    g2 = bf16_round(rng.normal(0, 1, (n, 2 * h, 2 * w, c)))
+    xt = torch.zeros((n, c, h, w), requires_grad=True)
+    F.interpolate(xt, scale_factor=2, mode="bilinear", align_corners=False).backward(
+        torch.from_numpy(g2).permute(0, 3, 1, 2))
+    L.check(lib.miseg_upsample_bilinear2x_bwd(dbf(g2, dev).data_ptr(), dx.data_ptr(), n, h, w, c, c, c, None))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-2, atol=2e-2)
+    # channel-slice copy with accumulate, channel sums
+    a = bf16_round(rng.normal(0, 1, (n, h, w, c)))
+    b = bf16_round(rng.normal(0, 1, (n, h, w, 2 * c)))
+    ad, bd = dbf(a, dev), dbf(b, dev)
+    L.check(lib.miseg_copy_channels(ad.data_ptr(), bd.data_ptr() + 2 * c, bd.data_ptr() + 2 * c, n * h * w, c,
+                                    c, 2 * c, 2 * c, None))
+    got = bd.float().cpu().numpy()
+    np.testing.assert_array_equal(got[..., :c], b[..., :c])
+    np.testing.assert_array_equal(got[..., c:], bf16_round(a + b[..., c:]))
+    sums = torch.zeros(c, dtype=torch.float64, device=dev)
+    L.check(lib.miseg_channel_sums(ad.data_ptr(), n * h * w, c, c, sums.data_ptr(), None))
+    np.testing.assert_allclose(sums.cpu().numpy(), a.reshape(-1, c).astype(np.float64).sum(0), rtol=1e-5, atol=1e-4)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("classes,temp", [(3, 1.0), (3, 0.1), (2, 1.0), (4, 1.0)])
+def test_loss_grad_matches_autograd(env, classes, temp):
+    L, lib, dev = env
+    rng = np.random.default_rng(4)
+    n, h, w = 2, 10, 12
+    z = rng.normal(0, 1.5, (n, h, w, classes)).astype(np.float32)
+    gt = np.eye(classes, dtype=np.float32)[rng.integers(0, classes, (n, h, w))]
+    zt = torch.from_numpy(z).requires_grad_(True)
+    pr = torch.softmax(zt / temp, dim=-1)
+    g = torch.from_numpy(gt)
+    q = torch.clamp(pr / pr.sum(-1, keepdim=True), 1e-7, 1 - 1e-7)
+    cce = torch.mean(-g * torch.log(q))
+    tp = (g * pr).sum((0, 1, 2))
+    score = (2 * tp + 1e-5) / (g.sum((0, 1, 2)) + pr.sum((0, 1, 2)) + 1e-5)
+    loss = 0.5 * (cce + 1 - score.mean())
+    loss.backward()
+    prd, gtd = df32(pr.detach().numpy(), dev), df32(gt, dev)
+    sums = torch.zeros(4 * classes, dtype=torch.float64, device=dev)
+    L.check(lib.miseg_loss_sums(gtd.data_ptr(), prd.data_ptr(), sums.data_ptr(), n * h * w, classes, None))
+    dz = torch.zeros((n, h, w, 8), dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_loss_grad(gtd.data_ptr(), prd.data_ptr(), sums.data_ptr(), dz.data_ptr(), n * h * w,
+                                classes, 8, 0.5, temp, 1, 1, None))
+    torch.cuda.synchronize()
+    got = dz.float().cpu().numpy()
+    want = zt.grad.numpy()
+    np.testing.assert_allclose(got[..., :classes], want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
+    assert np.all(got[..., classes:] == 0)
+
+
+def test_adam_keras_form(env):
+    L, lib, dev = env
+    rng = np.random.default_rng(6)
+    cnt = 10007
+    p0 = rng.normal(0, 1, cnt).astype(np.float32)
+    g = rng.normal(0, 0.1, cnt).astype(np.float32)
+    m0 = rng.normal(0, 0.01, cnt).astype(np.float32)
+    v0 = rng.uniform(0, 0.01, cnt).astype(np.float32)
+    lr, b1, b2, eps, t = 1e-3, 0.9, 0.999, 1e-7, 3
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    p, m, v, gd = df32(p0, dev), df32(m0, dev), df32(v0, dev), df32(g, dev)
+    pb = torch.zeros(cnt, dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_adam_step(p.data_ptr(), m.data_ptr(), v.data_ptr(), gd.data_ptr(), pb.data_ptr(), cnt,
+                                lr_t, b1, b2, eps, 2.0, None))
+    torch.cuda.synchronize()
+    g2 = g * 2.0
+    m1 = b1 * m0 + (1 - b1) * g2
+    v1 = b2 * v0 + (1 - b2) * g2 * g2
+    p1 = p0 - lr_t * m1 / (np.sqrt(v1) + eps)
+    # the device contracts a*b+c into fma: a few fp32 ulps of difference
+    np.testing.assert_allclose(m.cpu().numpy(), m1, rtol=2e-5, atol=1e-8)
+    np.testing.assert_allclose(v.cpu().numpy(), v1, rtol=2e-5, atol=1e-10)
+    np.testing.assert_allclose(p.cpu().numpy(), p1, rtol=2e-5, atol=1e-6)
+    np.testing.assert_array_equal(pb.float().cpu().numpy(), bf16_round(p.cpu().numpy()))
