@@ -1,0 +1,773 @@
+"""Training step (forward with batch statistics, backward, Keras-form Adam) for every
+network `make_model` builds, executed layer by layer over the netspec.Graph on libmiseg.so
+kernels: the replacement of the tf.keras `Model.fit` inner loop the reference drives at
+/root/reference model_train.py:284-329 (loss and metrics chosen at :172-179, Adam at
+utils/model.py:234).
+
+Layout and precision: activations and activation gradients are bf16 NHWC (channels padded to a
+multiple of 32 with zeros), accumulation is fp32, parameters live in three flat fp32 buffers
+(value, Adam m, Adam v) plus a flat fp32 gradient buffer and a flat bf16 working copy that the
+forward convolutions read directly.  Convolution kernels are stored in the layout the kernels
+consume, [Cout][KH][KW][Cin] (transpose-conv: [phase][Cout][2][2][Cin]), so the weight-gradient
+kernel writes straight into the gradient buffer and Adam is one launch over the flat buffers.
+Data gradients reuse the forward convolution kernels on re-packed (flipped / transposed)
+weights.  torch supplies device memory, streams, the tiny weight re-packing copies and the
+collective (RCCL all-reduce of the flat gradient buffer in buckets, issued while the backward
+pass is still running).
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import lib as L
+
+
+def _c32(c):
+    return (c + 31) // 32 * 32
+
+
+class Act:
+    """bf16 NHWC activation (or gradient) view: channels [c0, c0 + c) of `t`."""
+
+    def __init__(self, t, c, c0=0):
+        self.t, self.c, self.c0 = t, c, c0
+
+    @property
+    def n(self):
+        return self.t.shape[0]
+
+    @property
+    def h(self):
+        return self.t.shape[1]
+
+    @property
+    def w(self):
+        return self.t.shape[2]
+
+    @property
+    def pix(self):
+        return self.t.shape[3]
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 2 * self.c0
+
+    @property
+    def pixels(self):
+        return self.n * self.h * self.w
+
+    def slice(self, c0, c):
+        return Act(self.t, c, self.c0 + c0)
+
+    def float(self):
+        return self.t[..., self.c0:self.c0 + self.c].float()
+
+
+class Seg:
+    """One parameter tensor inside the flat buffers."""
+
+    def __init__(self, off, count, shape):
+        self.off, self.count, self.shape = off, count, shape
+
+
+class Trainer:
+    def __init__(self, graph, weights, batch, device="cuda:0", learning_rate=1e-3, beta_1=0.9,
+                 beta_2=0.999, epsilon=1e-7, loss="cce_dice", world_size=1, bucket_mb=25):
+        if not torch.cuda.is_available():
+            raise L.MisegError("no GPU visible: the HIP training path has no CPU fallback")
+        self.lib = L.load()
+        self.dev = torch.device(device)
+        torch.cuda.set_device(self.dev)
+        L.check(self.lib.miseg_device_check())
+        self.g = graph
+        self.n = batch
+        self.H, self.W, _ = graph.input_shape
+        self.classes = graph.classes
+        if self.classes < 2:
+            raise NotImplementedError("training of the single-class (sigmoid) head is not built yet")
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta_1, beta_2, epsilon
+        self.step_count = 0
+        self.use_cce = loss in ("cce_dice", "categorical_crossentropy_plus_dice_loss", "cce",
+                                "categorical_crossentropy")
+        self.use_dice = loss in ("cce_dice", "categorical_crossentropy_plus_dice_loss", "dice", "dice_loss")
+        if not (self.use_cce or self.use_dice):
+            raise NotImplementedError("loss %r is not built on the HIP path" % (loss,))
+        self.world = world_size
+        self.bucket_bytes = int(bucket_mb * 2 ** 20)
+        self._analyse()
+        self._alloc_params(weights)
+        self._pending = []
+        self.keep_grads = False       # debugging: keep (dy, dx) of every layer of the last backward
+        self.grad_log = None
+
+    # ------------------------------------------------------------------ graph analysis
+    def _analyse(self):
+        g = self.g
+        self.consumers = {n: [] for n in g.layers}
+        for l in g.layers.values():
+            for i in l.inbound:
+                self.consumers[i].append(l.name)
+        self.order = list(g.layers)
+
+    def _src(self, name):
+        """Skip ZeroPadding2D: returns (producer layer name, accumulated padding)."""
+        pad = 0
+        l = self.g.layers[name]
+        while l.cls == "ZeroPadding2D":
+            pad += l.config["padding"]
+            l = self.g.layers[l.inbound[0]]
+        return l.name, pad
+
+    # ------------------------------------------------------------------ parameters
+    def _alloc_params(self, weights):
+        g = self.g
+        segs = OrderedDict()      # (layer, weight) -> Seg
+        off = 0
+
+        def add(key, count, shape):
+            nonlocal off
+            segs[key] = Seg(off, count, shape)
+            off += (count + 63) // 64 * 64       # 256-byte aligned segments
+
+        self.conv_info = {}
+        for l in g.layers.values():
+            if l.cls == "Conv2D":
+                kh, kw, ci, co = l.weights[0][1]
+                co8 = (co + 7) // 8 * 8          # the weight-gradient kernel writes whole groups of 8 rows
+                if kh == 7:
+                    shape = (co8, 7, 1, 32)
+                else:
+                    shape = (co8, kh, kw, _c32(ci))
+                add((l.name, "kernel"), int(np.prod(shape)), shape)
+                if l.config["use_bias"]:
+                    add((l.name, "bias"), co, (co,))
+            elif l.cls == "Conv2DTranspose":
+                _, _, co, ci = l.weights[0][1]
+                shape = (4, co, 2, 2, _c32(ci))
+                add((l.name, "kernel"), int(np.prod(shape)), shape)
+            elif l.cls == "BatchNormalization":
+                c = l.out.c
+                if l.config["scale"]:
+                    add((l.name, "gamma"), c, (c,))
+                add((l.name, "beta"), c, (c,))
+        self.segs = segs
+        self.nparam = off
+        dev = self.dev
+        self.P = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.G = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.M = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.V = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.PB = torch.zeros(off, dtype=torch.bfloat16, device=dev)
+        # non-trainable moving statistics and per-step BN scratch
+        self.moving = {}
+        self.bn_state = {}
+        for l in g.layers.values():
+            if l.cls == "BatchNormalization":
+                c = l.out.c
+                self.moving[l.name] = (torch.zeros(c, device=dev), torch.ones(c, device=dev))
+                cp = max(c, 8)
+                self.bn_state[l.name] = {k: torch.zeros(cp, device=dev) for k in ("mean", "var", "scale", "shift")}
+                self.bn_state[l.name]["ws"] = torch.zeros(2 * cp, dtype=torch.float64, device=dev)
+        self.stem_mask = None
+        self.set_weights(weights)
+
+    def view(self, layer, wname):
+        s = self.segs[(layer, wname)]
+        return self.P[s.off:s.off + s.count].view(s.shape)
+
+    def gview(self, layer, wname):
+        s = self.segs[(layer, wname)]
+        return self.G[s.off:s.off + s.count].view(s.shape)
+
+    def wptr(self, layer, wname="kernel"):
+        return self.PB.data_ptr() + 2 * self.segs[(layer, wname)].off
+
+    def set_weights(self, weights):
+        """weights: {layer: {name: np.ndarray}} in Keras layouts."""
+        for l in self.g.layers.values():
+            if l.name not in weights:
+                continue
+            w = weights[l.name]
+            if l.cls == "Conv2D":
+                k = torch.from_numpy(np.ascontiguousarray(w["kernel"], dtype=np.float32)).to(self.dev)
+                kh, kw, ci, co = k.shape
+                v = self.view(l.name, "kernel")
+                v.zero_()
+                if kh == 7:
+                    v5 = v.view(-1, 7, 1, 8, 4)
+                    v5[:co, :, 0, :7, :3] = k.permute(3, 0, 1, 2)
+                    if self.stem_mask is None:
+                        m = torch.zeros_like(v5)
+                        m[:co, :, 0, :7, :3] = 1
+                        self.stem_mask = (l.name, m.view(v.shape))
+                else:
+                    v[:co, :, :, :ci] = k.permute(3, 0, 1, 2)
+                if "bias" in w:
+                    self.view(l.name, "bias").copy_(torch.from_numpy(np.asarray(w["bias"], np.float32)))
+            elif l.cls == "Conv2DTranspose":
+                k = torch.from_numpy(np.ascontiguousarray(w["kernel"], dtype=np.float32)).to(self.dev)
+                ci = k.shape[3]
+                v = self.view(l.name, "kernel")
+                v.zero_()
+                for a in range(2):
+                    for b in range(2):
+                        for dy in range(2):
+                            for dx in range(2):
+                                v[a * 2 + b, :, dy, dx, :ci] = k[3 - a - 2 * dy, 3 - b - 2 * dx]
+            elif l.cls == "BatchNormalization":
+                if "gamma" in w:
+                    self.view(l.name, "gamma").copy_(torch.from_numpy(np.asarray(w["gamma"], np.float32)))
+                self.view(l.name, "beta").copy_(torch.from_numpy(np.asarray(w["beta"], np.float32)))
+                mm, mv = self.moving[l.name]
+                mm.copy_(torch.from_numpy(np.asarray(w["moving_mean"], np.float32)))
+                mv.copy_(torch.from_numpy(np.asarray(w["moving_variance"], np.float32)))
+        self.PB.copy_(self.P)
+        self._dgrad_cache = {}
+
+    def get_weights(self):
+        """Back to {layer: {name: np.ndarray}} in Keras layouts."""
+        out = OrderedDict()
+        for l in self.g.layers.values():
+            if not l.weights:
+                continue
+            d = OrderedDict()
+            if l.cls == "Conv2D":
+                kh, kw, ci, co = l.weights[0][1]
+                v = self.view(l.name, "kernel")
+                if kh == 7:
+                    k = v.view(-1, 7, 1, 8, 4)[:co, :, 0, :7, :3].permute(1, 2, 3, 0)
+                else:
+                    k = v[:co, :, :, :ci].permute(1, 2, 3, 0)
+                d["kernel"] = k.contiguous().cpu().numpy()
+                if l.config["use_bias"]:
+                    d["bias"] = self.view(l.name, "bias").cpu().numpy().copy()
+            elif l.cls == "Conv2DTranspose":
+                _, _, co, ci = l.weights[0][1]
+                v = self.view(l.name, "kernel")
+                k = torch.zeros((4, 4, co, ci), device=self.dev)
+                for a in range(2):
+                    for b in range(2):
+                        for dy in range(2):
+                            for dx in range(2):
+                                k[3 - a - 2 * dy, 3 - b - 2 * dx] = v[a * 2 + b, :, dy, dx, :ci]
+                d["kernel"] = k.cpu().numpy()
+            elif l.cls == "BatchNormalization":
+                if l.config["scale"]:
+                    d["gamma"] = self.view(l.name, "gamma").cpu().numpy().copy()
+                d["beta"] = self.view(l.name, "beta").cpu().numpy().copy()
+                d["moving_mean"] = self.moving[l.name][0].cpu().numpy().copy()
+                d["moving_variance"] = self.moving[l.name][1].cpu().numpy().copy()
+            out[l.name] = d
+        return out
+
+    # ------------------------------------------------------------------ kernel wrappers
+    def stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def new(self, h, w, c, zero=False):
+        cp = _c32(c)
+        if zero or cp != c:
+            t = torch.zeros((self.n, h, w, cp), dtype=torch.bfloat16, device=self.dev)
+        else:
+            t = torch.empty((self.n, h, w, cp), dtype=torch.bfloat16, device=self.dev)
+        return Act(t, c)
+
+    def conv(self, x, wptr, cout, kh, kw, sy, sx, py, px, out, ho, wo, bias=None, transposed=False,
+             out_view=None, act=L.ACT_NONE, probs=None, temperature=1.0):
+        """out_view: (ptr, pix, row, img) to address a strided lattice; default = dense `out`."""
+        d = L.ConvDesc()
+        d.inp, d.weight = x.ptr, wptr
+        d.N, d.H, d.W, d.Cin = x.n, x.h, x.w, _c32(x.c)
+        assert x.c0 + d.Cin <= x.pix, "input view lacks channel padding"
+        d.Ho, d.Wo, d.Cout = ho, wo, cout
+        d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = x.pix, x.pix * x.w, x.pix * x.w * x.h
+        if probs is not None:
+            d.out = probs.data_ptr()
+            c = probs.shape[-1]
+            d.out_pix_stride, d.out_row_stride, d.out_img_stride = c, c * wo, c * wo * ho
+            d.out_dtype = L.DT_F32
+        elif out_view is not None:
+            d.out, d.out_pix_stride, d.out_row_stride, d.out_img_stride = out_view
+        else:
+            oh, ow = (2 * ho, 2 * wo) if transposed else (ho, wo)
+            assert (out.h, out.w) == (oh, ow), (out.h, out.w, oh, ow)
+            d.out = out.ptr
+            d.out_pix_stride, d.out_row_stride, d.out_img_stride = out.pix, out.pix * ow, out.pix * ow * oh
+        d.shift = bias
+        d.act = act
+        d.transposed = 1 if transposed else 0
+        d.temperature = temperature
+        L.check(self.lib.miseg_conv2d_fwd(C.byref(d), self.stream()))
+
+    def wgrad(self, x, dy_ptr, dy_strides, dw_ptr, cin, cout, kh, kw, sy, sx, py, px, ho, wo,
+              x_geom=None):
+        d = L.WgradDesc()
+        d.x, d.dy, d.dw = x.ptr, dy_ptr, dw_ptr
+        if x_geom is None:
+            d.N, d.H, d.W = x.n, x.h, x.w
+            d.x_pix, d.x_row, d.x_img = x.pix, x.pix * x.w, x.pix * x.w * x.h
+        else:
+            d.N, d.H, d.W, d.x_pix, d.x_row, d.x_img = x_geom
+        d.Cin, d.Ho, d.Wo, d.Cout = cin, ho, wo, cout
+        d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
+        d.dy_pix, d.dy_row, d.dy_img = dy_strides
+        L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.stream()))
+
+    def add_into(self, a, b, c=None):
+        """returns a + b (bf16) as a new tensor."""
+        c = c or a.c
+        out = self.new(a.h, a.w, c)
+        L.check(self.lib.miseg_copy_channels(a.ptr, b.ptr, out.ptr, a.pixels, c, a.pix, b.pix, out.pix,
+                                             self.stream()))
+        return out
+
+    def copy(self, src, dst, c):
+        L.check(self.lib.miseg_copy_channels(src.ptr, None, dst.ptr, src.pixels, c, src.pix, 0, dst.pix,
+                                             self.stream()))
+
+    # ------------------------------------------------------------------ dgrad weight packs
+    def dgrad_weight(self, l):
+        """bf16 weights of the convolution that maps dY to dX, re-packed from the master copy.
+        Returns a list of (weight tensor, kh, kw, taps description) per output phase."""
+        key = l.name
+        if key in self._dgrad_cache:
+            return self._dgrad_cache[key]
+        if l.cls == "Conv2D":
+            kh, kw, ci, co = l.weights[0][1]
+            s = l.config["strides"]
+            v = self.view(l.name, "kernel")[:co, :, :, :ci]            # [co][kh][kw][ci]
+            cop = _c32(co)
+
+            def pack(sub):                                            # sub: [co][th][tw][ci]
+                t = torch.zeros((ci, sub.shape[1], sub.shape[2], cop), dtype=torch.bfloat16, device=self.dev)
+                t[..., :co] = sub.permute(3, 1, 2, 0)
+                return t
+            if s == 1:
+                packs = [pack(v.flip(1, 2))]
+            else:
+                # dX[2y+a, 2x+b] = sum_t dY[y+ty, x+tx] W[ky(a,ty), kx(b,tx)]; pad = (k-1)//2
+                p = (kh - 1) // 2
+                packs = []
+                for a in range(2):
+                    for b in range(2):
+                        kys = [k for k in range(kh) if (a + p - k) % 2 == 0]
+                        kxs = [k for k in range(kw) if (b + p - k) % 2 == 0]
+                        # tap offset t = (a + p - k) / 2 ... input row y + t? out row oy = (2y+a+p-k)/2
+                        kys = sorted(kys, key=lambda k: (a + p - k) // 2)
+                        kxs = sorted(kxs, key=lambda k: (b + p - k) // 2)
+                        oys = [(a + p - k) // 2 for k in kys]
+                        oxs = [(b + p - k) // 2 for k in kxs]
+                        if not kys or not kxs:
+                            packs.append(None)
+                            continue
+                        sub = v[:, kys][:, :, kxs]
+                        packs.append((pack(sub), oys[0], oxs[0], len(kys), len(kxs)))
+            self._dgrad_cache[key] = packs
+            return packs
+        # Conv2DTranspose: dIn = 4x4 stride-2 pad-1 convolution of dOut with K[kh][kw][co][ci]
+        _, _, co, ci = l.weights[0][1]
+        v = self.view(l.name, "kernel")                                # [4][co][2][2][cip]
+        k = torch.zeros((ci, 4, 4, _c32(co)), dtype=torch.bfloat16, device=self.dev)
+        for a in range(2):
+            for b in range(2):
+                for dy in range(2):
+                    for dx in range(2):
+                        k[:, 3 - a - 2 * dy, 3 - b - 2 * dx, :co] = v[a * 2 + b, :, dy, dx, :ci].t()
+        self._dgrad_cache[key] = [k]
+        return [k]
+
+    # ------------------------------------------------------------------ forward (training mode)
+    def forward(self, x, momentum_update=True):
+        """x: fp32 (n,H,W,3) device tensor.  Returns fp32 probabilities (n,H,W,classes)."""
+        g, lib, st = self.g, self.lib, self.stream()
+        self.acts = {}
+        self.saved = {}
+        n = self.n
+        self.x_in = x.contiguous()
+        for name in self.order:
+            l = g.layers[name]
+            cls = l.cls
+            if cls in ("InputLayer", "ZeroPadding2D"):
+                continue
+            if cls == "BatchNormalization" and g.layers[l.inbound[0]].cls == "InputLayer":
+                # bn_data: batch statistics of the fp32 input; applied by the stem's input preparation
+                s = self.bn_state[name]
+                mm, mv = self.moving[name] if momentum_update else (None, None)
+                L.check(lib.miseg_input_stats_fwd(
+                    self.x_in.data_ptr(), n * self.H * self.W, self.view(name, "beta").data_ptr(),
+                    mm.data_ptr() if mm is not None else None, mv.data_ptr() if mv is not None else None,
+                    l.config["momentum"], l.config["epsilon"], s["mean"].data_ptr(), s["var"].data_ptr(),
+                    s["scale"].data_ptr(), s["shift"].data_ptr(), s["ws"].data_ptr(), st))
+                continue
+            if cls == "Conv2D":
+                src, pad = self._src(l.inbound[0])
+                k = l.config["kernel_size"]
+                stride = l.config["strides"]
+                if l.config["padding"] == "same":
+                    pad = (k - 1) // 2
+                co = l.out.c
+                bias = self.view(name, "bias").data_ptr() if l.config["use_bias"] else None
+                if k == 7:
+                    self._stem_forward(l, src)
+                    continue
+                xin = self.acts[src]
+                out = self.new(l.out.h, l.out.w, co)
+                if name == g.logits_layer:
+                    probs = torch.empty((n, l.out.h, l.out.w, co), dtype=torch.float32, device=self.dev)
+                    act = L.ACT_SIGMOID if g.activation == "sigmoid" else L.ACT_SOFTMAX
+                    self.conv(xin, self.wptr(name), co, k, k, stride, stride, pad, pad, None, l.out.h,
+                              l.out.w, bias=bias, act=act, probs=probs,
+                              temperature=g.temperature if g.temperature else 1.0)
+                    self.probs = probs
+                    self.saved[name] = (xin, pad)
+                    continue
+                self.conv(xin, self.wptr(name), co, k, k, stride, stride, pad, pad, out, l.out.h, l.out.w,
+                          bias=bias)
+                self.acts[name] = out
+                self.saved[name] = (xin, pad)
+            elif cls == "Conv2DTranspose":
+                xin = self.acts[l.inbound[0]]
+                out = self.new(l.out.h, l.out.w, l.out.c)
+                self.conv(xin, self.wptr(name), l.out.c, 2, 2, 1, 1, 0, 0, out, xin.h, xin.w, transposed=True)
+                self.acts[name] = out
+                self.saved[name] = (xin, 0)
+            elif cls == "BatchNormalization":
+                xin = self.acts[l.inbound[0]]
+                s = self.bn_state[name]
+                c = l.out.c
+                mm, mv = self.moving[name] if momentum_update else (None, None)
+                gamma = self.view(name, "gamma").data_ptr() if l.config["scale"] else None
+                L.check(lib.miseg_bn_stats_fwd(
+                    xin.ptr, xin.pixels, c, xin.pix, gamma, self.view(name, "beta").data_ptr(),
+                    mm.data_ptr() if mm is not None else None, mv.data_ptr() if mv is not None else None,
+                    l.config["momentum"], l.config["epsilon"], s["mean"].data_ptr(), s["var"].data_ptr(),
+                    s["scale"].data_ptr(), s["shift"].data_ptr(), s["ws"].data_ptr(), st))
+                cons = self.consumers[name]
+                relu = len(cons) == 1 and g.layers[cons[0]].cls == "Activation" and \
+                    g.layers[cons[0]].config["activation"] == "relu"
+                if not relu:
+                    raise NotImplementedError("BatchNormalization without a following ReLU: %s" % name)
+                out = self.new(xin.h, xin.w, c)
+                L.check(lib.miseg_scale_shift_relu_fwd(xin.ptr, out.ptr, s["scale"].data_ptr(),
+                                                       s["shift"].data_ptr(), xin.pixels, c, xin.pix,
+                                                       out.pix, st))
+                self.acts[cons[0]] = out          # the ReLU's output
+                self.saved[name] = xin
+            elif cls == "Activation":
+                continue                           # relu: fused with its BatchNormalization; softmax: head
+            elif cls == "TemperatureScaledSoftmax":
+                continue
+            elif cls == "MaxPooling2D":
+                src, _ = self._src(l.inbound[0])
+                xin = self.acts[src]
+                out = self.new(l.out.h, l.out.w, l.out.c)
+                L.check(lib.miseg_maxpool3x3s2_fwd(xin.ptr, out.ptr, None, None, n, xin.h, xin.w, xin.c,
+                                                   xin.pix, out.pix, st))
+                self.acts[name] = out
+                self.saved[name] = xin
+            elif cls == "AveragePooling2D":
+                xin = self.acts[l.inbound[0]]
+                out = self.new(l.out.h, l.out.w, l.out.c)
+                L.check(lib.miseg_avgpool2x2_fwd(xin.ptr, out.ptr, n, xin.h, xin.w, xin.c, xin.pix, out.pix, st))
+                self.acts[name] = out
+            elif cls == "UpSampling2D":
+                xin = self.acts[l.inbound[0]]
+                out = self.new(l.out.h, l.out.w, l.out.c)
+                if l.config["interpolation"] == "bilinear":
+                    L.check(lib.miseg_upsample_bilinear2x_fwd(xin.ptr, out.ptr, n, xin.h, xin.w, xin.c,
+                                                              xin.pix, out.pix, st))
+                else:
+                    shift = int(round(math.log2(l.config["size"])))
+                    L.check(lib.miseg_upsample_nearest_fwd(xin.ptr, None, out.ptr, n, xin.h, xin.w, xin.c,
+                                                           shift, xin.pix, 0, out.pix, st))
+                self.acts[name] = out
+            elif cls == "Add":
+                a, b = self.acts[l.inbound[0]], self.acts[l.inbound[1]]
+                self.acts[name] = self.add_into(a, b, l.out.c)
+            elif cls == "Concatenate":
+                out = self.new(l.out.h, l.out.w, l.out.c)
+                c0 = 0
+                for i in l.inbound:
+                    src = self.acts[i]
+                    self.copy(src, out.slice(c0, src.c), src.c)
+                    c0 += src.c
+                self.acts[name] = out
+            else:
+                raise NotImplementedError("layer class %s" % cls)
+        return self.probs
+
+    def _stem_forward(self, l, src):
+        lib, st, n = self.lib, self.stream(), self.n
+        h, w = self.H, self.W
+        padded = torch.empty((n, h + 6, w + 8, 4), dtype=torch.bfloat16, device=self.dev)
+        srcl = self.g.layers[src]
+        if srcl.cls == "BatchNormalization":
+            s = self.bn_state[src]
+            sc, sh = s["scale"], s["shift"]
+        else:
+            sc = torch.ones(8, device=self.dev)
+            sh = torch.zeros(8, device=self.dev)
+        L.check(lib.miseg_prep_input(self.x_in.data_ptr(), padded.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                                     n, h, w, st))
+        # channel 3 = indicator of "inside the image": the stem's weight gradient for that (dead)
+        # channel then equals the per-tap sums of dY that the input BatchNorm's beta gradient needs
+        padded[:, 3:3 + h, 3:3 + w, 3] = 1.0
+        out = self.new(h // 2, w // 2, 64)
+        d = L.ConvDesc()
+        d.inp, d.weight = padded.data_ptr(), self.wptr(l.name)
+        d.N, d.H, d.W, d.Cin = n, h + 6, w // 2, 32
+        d.Ho, d.Wo, d.Cout = h // 2, w // 2, 64
+        d.KH, d.KW, d.stride_y, d.stride_x = 7, 1, 2, 1
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = 8, (w + 8) * 4, (h + 6) * (w + 8) * 4
+        d.out = out.ptr
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = out.pix, out.pix * (w // 2), out.pix * (w // 2) * (h // 2)
+        d.temperature = 1.0
+        L.check(lib.miseg_conv2d_fwd(C.byref(d), st))
+        self.acts[l.name] = out
+        self.saved[l.name] = (padded, src)
+
+    # ------------------------------------------------------------------ loss
+    def loss_and_metrics(self, gt):
+        """gt: fp32 one-hot (n,H,W,classes) device tensor.  Returns dict and keeps the sums."""
+        c = self.classes
+        self.gt = gt.contiguous()
+        self.loss_sums = torch.empty(4 * c, dtype=torch.float64, device=self.dev)
+        pixels = self.n * self.H * self.W
+        L.check(self.lib.miseg_loss_sums(self.gt.data_ptr(), self.probs.data_ptr(), self.loss_sums.data_ptr(),
+                                         pixels, c, self.stream()))
+        return self.loss_sums, pixels
+
+    # ------------------------------------------------------------------ backward
+    def _accum(self, grads, name, gact, producer=None, dy=None):
+        if self.grad_log is not None:
+            if producer is not None:
+                self.grad_log[producer] = (dy, gact)
+            self.accum_log.setdefault(name, []).append(gact)
+        if name in grads:
+            grads[name] = self.add_into(grads[name], gact, gact.c)
+        else:
+            grads[name] = gact
+
+    def backward(self, loss_scale=1.0):
+        g, lib, st, n = self.g, self.lib, self.stream(), self.n
+        self.G.zero_()
+        grads = {}
+        self.grad_log = {} if self.keep_grads else None
+        self.accum_log, self.accum_final = {}, {}
+        c = self.classes
+        head = g.layers[g.logits_layer]
+        dz = torch.zeros((n, self.H, self.W, 32), dtype=torch.bfloat16, device=self.dev)
+        temp = g.temperature if g.temperature else 1.0
+        L.check(lib.miseg_loss_grad(self.gt.data_ptr(), self.probs.data_ptr(), self.loss_sums.data_ptr(),
+                                    dz.data_ptr(), n * self.H * self.W, c, 32, loss_scale, temp,
+                                    1 if self.use_cce else 0, 1 if self.use_dice else 0, st))
+        grads[head.name] = Act(dz, c)
+        bucket_hi = self.nparam
+        for name in reversed(self.order):
+            l = g.layers[name]
+            cls = l.cls
+            if cls in ("InputLayer", "ZeroPadding2D", "TemperatureScaledSoftmax"):
+                continue
+            if cls == "Activation":
+                if l.config["activation"] == "relu" and name in grads:
+                    # hand the gradient to the BatchNormalization this ReLU is fused with
+                    if self.grad_log is not None:
+                        self.accum_final[name] = grads[name]
+                    grads[l.inbound[0]] = grads.pop(name)
+                continue
+            if cls == "BatchNormalization" and g.layers[l.inbound[0]].cls == "InputLayer":
+                continue                      # bn_data: handled with the stem
+            if name not in grads:
+                continue
+            dy = grads.pop(name)
+            if self.grad_log is not None:
+                self.accum_final[name] = dy
+            if cls == "Conv2D":
+                self._conv_backward(l, dy, grads)
+            elif cls == "Conv2DTranspose":
+                self._convT_backward(l, dy, grads)
+            elif cls == "BatchNormalization":
+                xin = self.saved[name]
+                s = self.bn_state[name]
+                cc = l.out.c
+                sums = torch.empty(2 * cc, dtype=torch.float64, device=self.dev)
+                L.check(lib.miseg_bn_relu_bwd_reduce(xin.ptr, dy.ptr, xin.pixels, cc, xin.pix, dy.pix,
+                                                     s["scale"].data_ptr(), s["shift"].data_ptr(),
+                                                     s["mean"].data_ptr(), s["var"].data_ptr(),
+                                                     l.config["epsilon"], 1, sums.data_ptr(), st))
+                dx = self.new(xin.h, xin.w, cc)
+                L.check(lib.miseg_bn_relu_bwd_apply(xin.ptr, dy.ptr, dx.ptr, xin.pixels, cc, xin.pix, dy.pix,
+                                                    dx.pix, s["scale"].data_ptr(), s["shift"].data_ptr(),
+                                                    s["mean"].data_ptr(), s["var"].data_ptr(),
+                                                    l.config["epsilon"], 1, sums.data_ptr(), st))
+                self.gview(name, "beta").copy_(sums[:cc])
+                if l.config["scale"]:
+                    self.gview(name, "gamma").copy_(sums[cc:])
+                self._accum(grads, l.inbound[0], dx, name, dy)
+            elif cls == "MaxPooling2D":
+                xin = self.saved[name]
+                dx = self.new(xin.h, xin.w, xin.c)
+                L.check(lib.miseg_maxpool3x3s2_bwd(xin.ptr, dy.ptr, dx.ptr, n, xin.h, xin.w, xin.c, xin.pix,
+                                                   dy.pix, dx.pix, st))
+                self._accum(grads, self._src(l.inbound[0])[0], dx, name, dy)
+            elif cls == "AveragePooling2D":
+                src = g.layers[l.inbound[0]].out
+                dx = self.new(src.h, src.w, src.c)
+                L.check(lib.miseg_avgpool2x2_bwd(dy.ptr, dx.ptr, n, src.h, src.w, src.c, dy.pix, dx.pix, st))
+                self._accum(grads, l.inbound[0], dx, name, dy)
+            elif cls == "UpSampling2D":
+                src = g.layers[l.inbound[0]].out
+                dx = self.new(src.h, src.w, src.c)
+                if l.config["interpolation"] == "bilinear":
+                    L.check(lib.miseg_upsample_bilinear2x_bwd(dy.ptr, dx.ptr, n, src.h, src.w, src.c, dy.pix,
+                                                              dx.pix, st))
+                else:
+                    shift = int(round(math.log2(l.config["size"])))
+                    L.check(lib.miseg_upsample_nearest_bwd(dy.ptr, dx.ptr, n, src.h, src.w, src.c, shift,
+                                                           dy.pix, dx.pix, st))
+                self._accum(grads, l.inbound[0], dx, name, dy)
+            elif cls == "Add":
+                for i in l.inbound:
+                    self._accum(grads, i, dy)
+            elif cls == "Concatenate":
+                c0 = 0
+                for i in l.inbound:
+                    ci = g.layers[i].out.c
+                    part = self.new(dy.h, dy.w, ci)
+                    self.copy(dy.slice(c0, ci), part, ci)
+                    self._accum(grads, i, part)
+                    c0 += ci
+            else:
+                raise NotImplementedError("backward of %s" % cls)
+            bucket_hi = self._maybe_allreduce(name, bucket_hi)
+        self._maybe_allreduce(None, bucket_hi, flush=True)
+
+    def _conv_backward(self, l, dy, grads):
+        lib, st, n = self.lib, self.stream(), self.n
+        name = l.name
+        k = l.config["kernel_size"]
+        stride = l.config["strides"]
+        co = l.out.c
+        cop = _c32(co)
+        if l.config["use_bias"]:
+            sums = torch.empty(cop, dtype=torch.float64, device=self.dev)
+            L.check(lib.miseg_channel_sums(dy.ptr, dy.pixels, cop, dy.pix, sums.data_ptr(), st))
+            self.gview(name, "bias").copy_(sums[:co])
+        seg = self.segs[(name, "kernel")]
+        dw_ptr = self.G.data_ptr() + 4 * seg.off
+        dy_str = (dy.pix, dy.pix * dy.w, dy.pix * dy.w * dy.h)
+        if k == 7:
+            padded, src = self.saved[name]
+            h, w = self.H, self.W
+            self.wgrad(Act(padded, 4), dy.ptr, dy_str, dw_ptr, 32, co, 7, 1, 2, 1, 0, 0, h // 2, w // 2,
+                       x_geom=(n, h + 6, w // 2, 8, (w + 8) * 4, (h + 6) * (w + 8) * 4))
+            gk = self.gview(name, "kernel")
+            srcl = self.g.layers[src]
+            if srcl.cls == "BatchNormalization":
+                # d beta[c] = sum_{co,tap} W[co][tap][c] * (sum of dY over the taps' valid pixels); the
+                # indicator channel of the prepared input made the weight gradient hold those sums
+                g5 = gk.view(-1, 7, 1, 8, 4)
+                w5 = self.view(name, "kernel").view(-1, 7, 1, 8, 4).to(torch.bfloat16).float()  # as the forward used it
+                dbeta = (w5[..., :3] * g5[..., 3:4]).sum(dim=(0, 1, 2, 3))
+                self.gview(src, "beta").copy_(dbeta)
+            gk.mul_(self.stem_mask[1])
+            if self.grad_log is not None:
+                self.grad_log[name] = (dy, None)
+            return
+        xin, pad = self.saved[name]
+        cin = _c32(xin.c)
+        self.wgrad(xin, dy.ptr, dy_str, dw_ptr, cin, (co + 7) // 8 * 8, k, k, stride, stride, pad, pad,
+                   l.out.h, l.out.w)
+        # data gradient
+        src_name = self._src(l.inbound[0])[0]
+        if self.g.layers[src_name].cls == "InputLayer":
+            return
+        ci = xin.c
+        dx = self.new(xin.h, xin.w, ci, zero=(stride != 1))
+        packs = self.dgrad_weight(l)
+        dyv = Act(dy.t, cop)
+        if stride == 1:
+            self.conv(dyv, packs[0].data_ptr(), ci, k, k, 1, 1, pad, pad, dx, xin.h, xin.w)
+        else:
+            for ph, pk in enumerate(packs):
+                if pk is None:
+                    continue
+                wt, oy0, ox0, th, tw = pk
+                a, b = ph >> 1, ph & 1
+                hp, wp = (xin.h - a + 1) // 2, (xin.w - b + 1) // 2
+                view = (dx.ptr + 2 * (a * dx.pix * dx.w + b * dx.pix), 2 * dx.pix, 2 * dx.pix * dx.w,
+                        dx.pix * dx.w * dx.h)
+                # out[y, x] = sum_t dY[y + oy0 + ty, x + ox0 + tx] * wt  ->  pad = -offset
+                self.conv(dyv, wt.data_ptr(), ci, th, tw, 1, 1, -oy0, -ox0, None, hp, wp, out_view=view)
+        self._accum(grads, src_name, dx, l.name, dy)
+
+    def _convT_backward(self, l, dy, grads):
+        name = l.name
+        xin, _ = self.saved[name]
+        co = l.out.c
+        cin = _c32(xin.c)
+        seg = self.segs[(name, "kernel")]
+        per_phase = co * 4 * cin
+        for a in range(2):
+            for b in range(2):
+                dyp = dy.ptr + 2 * (a * dy.pix * dy.w + b * dy.pix)
+                self.wgrad(xin, dyp, (2 * dy.pix, 2 * dy.pix * dy.w, dy.pix * dy.w * dy.h),
+                           self.G.data_ptr() + 4 * (seg.off + (a * 2 + b) * per_phase), cin, co, 2, 2, 1, 1,
+                           1 - a, 1 - b, xin.h, xin.w)
+        src_name = l.inbound[0]
+        dx = self.new(xin.h, xin.w, xin.c)
+        wt = self.dgrad_weight(l)[0]
+        dyv = Act(dy.t, _c32(co))
+        self.conv(dyv, wt.data_ptr(), xin.c, 4, 4, 2, 2, 1, 1, dx, xin.h, xin.w)
+        self._accum(grads, src_name, dx, l.name, dy)
+
+    # ------------------------------------------------------------------ data parallel
+    def _maybe_allreduce(self, name, hi, flush=False):
+        """Gradients are produced from the end of the flat buffer towards its start; once the
+        not-yet-reduced tail exceeds the bucket size (or at the end) it is all-reduced on RCCL
+        while the rest of the backward pass keeps running."""
+        if self.world <= 1:
+            return hi
+        import torch.distributed as dist
+        if flush:
+            lo = 0
+        else:
+            l = self.g.layers[name]
+            offs = [s.off for (ln, _), s in self.segs.items() if ln == name]
+            if not offs:
+                return hi
+            lo = min(offs)
+            if (hi - lo) * 4 < self.bucket_bytes:
+                return hi
+        if hi > lo:
+            self._pending.append(dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        return lo
+
+    def wait_allreduce(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    # ------------------------------------------------------------------ optimiser
+    def adam_step(self):
+        self.wait_allreduce()
+        self.step_count += 1
+        t = self.step_count
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        L.check(self.lib.miseg_adam_step(self.P.data_ptr(), self.M.data_ptr(), self.V.data_ptr(),
+                                         self.G.data_ptr(), self.PB.data_ptr(), self.nparam, lr_t, self.b1,
+                                         self.b2, self.eps, 1.0, self.stream()))
+        self._dgrad_cache = {}
+
+    def train_step(self, x, gt):
+        """One optimisation step on a local batch.  Returns (sums, pixels) of the forward pass for
+        loss / metric logging (segmentation_models sums, see losses.py)."""
+        self.forward(x)
+        sums, pixels = self.loss_and_metrics(gt)
+        self.backward(loss_scale=1.0 / self.world)
+        self.adam_step()
+        return sums, pixels

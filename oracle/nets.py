@@ -188,11 +188,18 @@ def init_weights(spec, seed=1234, randomize_bn=False):
 # forward graphs
 # ----------------------------------------------------------------------------
 class _Ctx:
-    def __init__(self, ops, weights, taps):
-        self.ops, self.w, self.taps = ops, weights, taps
+    def __init__(self, ops, weights, taps, training=False):
+        self.ops, self.w, self.taps, self.training = ops, weights, taps, training
+        self.batch_stats = OrderedDict()      # training mode: layer -> (mean, biased variance)
 
     def bn(self, x, name, eps):
         p = self.w[name]
+        if self.training:
+            # Keras BatchNormalization under model.fit (model_train.py:284): normalise with the
+            # statistics of the batch; the moving averages are updated from them on the side
+            y, mean, var = self.ops.batchnorm_train(x, p.get("gamma"), p["beta"], eps)
+            self.batch_stats[name] = (mean, var)
+            return y
         return self.ops.batchnorm(x, p.get("gamma"), p["beta"], p["moving_mean"],
                                   p["moving_variance"], eps)
 
@@ -320,11 +327,16 @@ def _fpn_decoder(c, x, feats):
 
 
 def forward(ops, encoder, decoder, weights, x, activation="softmax", temperature=1.0,
-            taps=None, return_logits=False):
-    """Inference-mode forward, model(batch, training=False) at
-    utils/predict.py:159.  `x`: (N,H,W,3) float32 in [0,1].  Returns
+            taps=None, return_logits=False, training=False, batch_stats=None):
+    """Forward pass: inference mode is model(batch, training=False) at
+    utils/predict.py:159; `training=True` is the forward half of a Model.fit step
+    (model_train.py:284), BatchNormalization on batch statistics, which are returned in
+    the dict `batch_stats` when one is passed.  `x`: (N,H,W,3) float32 in [0,1].  Returns
     probabilities (N,H,W,classes) as a back-end tensor (and logits if asked)."""
-    c = _Ctx(ops, {k: {n: ops.asarray(v) for n, v in d.items()} for k, d in weights.items()}, taps)
+    c = _Ctx(ops, {k: {n: ops.asarray(v) for n, v in d.items()} for k, d in weights.items()}, taps,
+             training)
+    if batch_stats is not None:
+        c.batch_stats = batch_stats
     x = ops.asarray(x)
     if encoder in RESNET_REPS:
         x, feats = _resnet_forward(c, x, RESNET_REPS[encoder])

@@ -74,6 +74,19 @@ def batchnorm(x, gamma, beta, mean, var, eps):
     return (x - mean) * inv + beta
 
 
+def batchnorm_train(x, gamma, beta, eps):
+    """Training-mode BatchNormalization(axis=3): normalise with the batch mean and the
+    biased batch variance (float64 accumulation); returns (y, mean, variance)."""
+    x64 = x.astype(np.float64)
+    mean = x64.mean(axis=(0, 1, 2))
+    var = ((x64 - mean) ** 2).mean(axis=(0, 1, 2))
+    inv = 1.0 / np.sqrt(var + eps)
+    if gamma is not None:
+        inv = inv * gamma
+    y = (x64 - mean) * inv + beta
+    return y.astype(np.float32), mean.astype(np.float32), var.astype(np.float32)
+
+
 def relu(x):
     return np.maximum(x, 0)
 

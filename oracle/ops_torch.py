@@ -55,6 +55,16 @@ def batchnorm(x, gamma, beta, mean, var, eps):
     return _nhwc(F.batch_norm(_nchw(x), _t(mean), _t(var), g, _t(beta), False, 0.0, eps))
 
 
+def batchnorm_train(x, gamma, beta, eps):
+    """Batch-statistics normalisation; returns (y, mean, biased variance)."""
+    mean = x.mean(dim=(0, 1, 2))
+    var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+    y = (x - mean) * torch.rsqrt(var + eps)
+    if gamma is not None:
+        y = y * _t(gamma)
+    return y + _t(beta), mean, var
+
+
 def relu(x):
     return F.relu(x)
 

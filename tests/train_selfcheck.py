@@ -1,0 +1,199 @@
+"""Layer-by-layer check of the HIP training step: every forward and backward op of a network is
+recomputed with torch (CPU, fp32 math, autograd) from the very tensors the trainer fed to its own
+kernel, so the comparison is free of the error amplification that a deep batch-normalised
+network adds to any end-to-end comparison of two bf16-storage runs.  Used by the GPU tests and by
+scripts/train_check.py."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def _bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def grads_as_weights(tr):
+    """The flat gradient buffer read through the Keras-layout weight views."""
+    P = tr.P
+    tr.P = tr.G
+    try:
+        return tr.get_weights()
+    finally:
+        tr.P = P
+
+
+def forward_errors(tr, weights):
+    g = tr.g
+    out = []
+    for name, l in g.layers.items():
+        if l.cls == "Conv2D" and name in tr.acts and l.config["kernel_size"] != 7:
+            xin, pad = tr.saved[name]
+            wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1)
+            b = torch.from_numpy(weights[name]["bias"]) if "bias" in weights[name] else None
+            ref = F.conv2d(xin.float().cpu().permute(0, 3, 1, 2), wt, b, stride=l.config["strides"],
+                           padding=pad).permute(0, 2, 3, 1)
+            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(ref))))
+        elif l.cls == "Conv2DTranspose":
+            xin, _ = tr.saved[name]
+            wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1)
+            ref = F.conv_transpose2d(xin.float().cpu().permute(0, 3, 1, 2), wt, stride=2, padding=1)
+            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(ref.permute(0, 2, 3, 1)))))
+        elif l.cls == "BatchNormalization" and name in tr.saved:
+            xf = tr.saved[name].float().cpu()
+            mean = xf.mean(dim=(0, 1, 2))
+            var = ((xf - mean) ** 2).mean(dim=(0, 1, 2))
+            gam = torch.from_numpy(weights[name]["gamma"]) if "gamma" in weights[name] else 1.0
+            ref = torch.relu((xf - mean) * torch.rsqrt(var + l.config["epsilon"]) * gam
+                             + torch.from_numpy(weights[name]["beta"]))
+            out.append((name, "fwd", _rel(tr.acts[tr.consumers[name][0]].float().cpu(), _bf(ref))))
+        elif l.cls == "Add":
+            ref = _bf(tr.acts[l.inbound[0]].float().cpu() + tr.acts[l.inbound[1]].float().cpu())
+            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), ref)))
+        elif l.cls == "Concatenate":
+            ref = torch.cat([tr.acts[i].float().cpu() for i in l.inbound], dim=-1)
+            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), ref)))
+        elif l.cls == "MaxPooling2D":
+            xf = tr.saved[name].float().cpu().permute(0, 3, 1, 2)
+            ref = F.max_pool2d(F.pad(xf, (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1)
+            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), ref)))
+        elif l.cls == "AveragePooling2D":
+            xf = tr.acts[l.inbound[0]].float().cpu().permute(0, 3, 1, 2)
+            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(F.avg_pool2d(xf, 2, 2).permute(0, 2, 3, 1)))))
+        elif l.cls == "UpSampling2D":
+            xf = tr.acts[l.inbound[0]].float().cpu().permute(0, 3, 1, 2)
+            if l.config["interpolation"] == "bilinear":
+                ref = F.interpolate(xf, scale_factor=2, mode="bilinear", align_corners=False)
+            else:
+                ref = F.interpolate(xf, scale_factor=l.config["size"], mode="nearest")
+            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(ref.permute(0, 2, 3, 1)))))
+    return out
+
+
+def backward_errors(tr, weights, x_input):
+    """Requires tr.keep_grads = True during backward()."""
+    g = tr.g
+    gw = grads_as_weights(tr)
+    out = []
+    nchw = lambda t: t.permute(0, 3, 1, 2)      # noqa: E731
+    nhwc = lambda t: t.permute(0, 2, 3, 1)      # noqa: E731
+    for name, l in g.layers.items():
+        if name not in tr.grad_log:
+            continue
+        dy, dx = tr.grad_log[name]
+        dyf = dy.float().cpu()
+        if l.cls == "Conv2D" and l.config["kernel_size"] != 7:
+            xin, pad = tr.saved[name]
+            xf = nchw(xin.float().cpu()).clone().requires_grad_(True)
+            wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1).clone().requires_grad_(True)
+            b = (torch.from_numpy(weights[name]["bias"]).clone().requires_grad_(True)
+                 if "bias" in weights[name] else None)
+            F.conv2d(xf, wt, b, stride=l.config["strides"], padding=pad).backward(nchw(dyf))
+            if dx is not None:
+                out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xf.grad))))
+            out.append((name, "dw", _rel(torch.from_numpy(gw[name]["kernel"]), wt.grad.permute(2, 3, 1, 0))))
+            if b is not None:
+                out.append((name, "dbias", _rel(torch.from_numpy(gw[name]["bias"]), b.grad)))
+        elif l.cls == "Conv2D":
+            # stem: input BatchNorm (when present) + 7x7 stride-2 convolution
+            xf = torch.from_numpy(x_input)
+            wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1).clone().requires_grad_(True)
+            bet = None
+            if "bn_data" in weights:
+                bet = torch.from_numpy(weights["bn_data"]["beta"]).clone().requires_grad_(True)
+                mean = xf.mean(dim=(0, 1, 2))
+                var = ((xf - mean) ** 2).mean(dim=(0, 1, 2))
+                xf = (xf - mean) * torch.rsqrt(var + g.layers["bn_data"].config["epsilon"]) + bet
+            xr = xf + (_bf(xf) - xf).detach()           # bf16 storage, straight-through gradient
+            F.conv2d(nchw(xr), wt, None, stride=2, padding=3).backward(nchw(dyf))
+            out.append((name, "dw", _rel(torch.from_numpy(gw[name]["kernel"]), wt.grad.permute(2, 3, 1, 0))))
+            if bet is not None:
+                out.append(("bn_data", "dbeta", _rel(torch.from_numpy(gw["bn_data"]["beta"]), bet.grad)))
+        elif l.cls == "Conv2DTranspose":
+            xin, _ = tr.saved[name]
+            xf = nchw(xin.float().cpu()).clone().requires_grad_(True)
+            wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1).clone().requires_grad_(True)
+            F.conv_transpose2d(xf, wt, stride=2, padding=1).backward(nchw(dyf))
+            out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xf.grad))))
+            out.append((name, "dw", _rel(torch.from_numpy(gw[name]["kernel"]), wt.grad.permute(2, 3, 1, 0))))
+        elif l.cls == "BatchNormalization":
+            xf = tr.saved[name].float().cpu().clone().requires_grad_(True)
+            gam = (torch.from_numpy(weights[name]["gamma"]).clone().requires_grad_(True)
+                   if "gamma" in weights[name] else None)
+            bet = torch.from_numpy(weights[name]["beta"]).clone().requires_grad_(True)
+            mean = xf.mean(dim=(0, 1, 2))
+            var = ((xf - mean) ** 2).mean(dim=(0, 1, 2))
+            y = (xf - mean) * torch.rsqrt(var + l.config["epsilon"])
+            if gam is not None:
+                y = y * gam
+            torch.relu(y + bet).backward(dyf)
+            out.append((name, "dx", _rel(dx.float().cpu(), xf.grad)))
+            if gam is not None:
+                out.append((name, "dgamma", _rel(torch.from_numpy(gw[name]["gamma"]), gam.grad)))
+            out.append((name, "dbeta", _rel(torch.from_numpy(gw[name]["beta"]), bet.grad)))
+        elif l.cls == "MaxPooling2D":
+            xf = nchw(tr.saved[name].float().cpu()).clone().requires_grad_(True)
+            F.max_pool2d(F.pad(xf, (1, 1, 1, 1)), 3, 2).backward(nchw(dyf))
+            out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xf.grad))))
+        elif l.cls == "AveragePooling2D":
+            xf = nchw(tr.acts[l.inbound[0]].float().cpu()).clone().requires_grad_(True)
+            F.avg_pool2d(xf, 2, 2).backward(nchw(dyf))
+            out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xf.grad))))
+        elif l.cls == "UpSampling2D":
+            xf = nchw(tr.acts[l.inbound[0]].float().cpu()).clone().requires_grad_(True)
+            if l.config["interpolation"] == "bilinear":
+                y = F.interpolate(xf, scale_factor=2, mode="bilinear", align_corners=False)
+            else:
+                y = F.interpolate(xf, scale_factor=l.config["size"], mode="nearest")
+            y.backward(nchw(dyf))
+            out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xf.grad))))
+    return out
+
+
+def accumulation_errors(tr):
+    """Every gradient a layer received must be the sum of one contribution per consumer."""
+    g = tr.g
+
+    def real_consumers(name):
+        n = 0
+        for c in tr.consumers[name]:
+            cl = g.layers[c]
+            if cl.cls == "ZeroPadding2D":
+                n += real_consumers(c)
+            elif cl.cls in ("Activation", "TemperatureScaledSoftmax") and cl.config.get("activation") != "relu":
+                continue
+            else:
+                n += 1
+        return n
+    out = []
+    for name, parts in tr.accum_log.items():
+        want = real_consumers(name)
+        total = parts[0].float().cpu()
+        for p in parts[1:]:
+            total = total + p.float().cpu()
+        seen = tr.accum_final[name].float().cpu()
+        out.append((name, "fanout %d/%d" % (len(parts), want), _rel(seen, total) if len(parts) == want else 1.0))
+    return out
+
+
+def run(encoder, decoder, h, w, n, classes=3, seed=0):
+    """One forward/backward of the HIP trainer on random data; returns (trainer, weights, x, gt)."""
+    import miseg_amd  # noqa: F401
+    from miseg_amd import netspec, trainer
+    from oracle import nets
+    spec = nets.build_spec(encoder, decoder, classes)
+    weights = nets.init_weights(spec, seed, True)
+    rng = np.random.default_rng(seed + 1)
+    x = rng.random((n, h, w, 3), dtype=np.float32)
+    gt = np.eye(classes, dtype=np.float32)[rng.integers(0, classes, (n, h, w))]
+    g = netspec.build_graph(encoder, decoder, (h, w, 3), classes, "softmax", None)
+    tr = trainer.Trainer(g, weights, n)
+    tr.keep_grads = True
+    tr.forward(torch.from_numpy(x).cuda())
+    tr.loss_and_metrics(torch.from_numpy(gt).cuda())
+    tr.backward()
+    torch.cuda.synchronize()
+    return tr, weights, x, gt
