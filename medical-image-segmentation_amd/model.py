@@ -186,11 +186,15 @@ class Model:
         return e
 
     def __call__(self, batch, training=False):
-        if training:
-            raise NotImplementedError("training-mode forward (batch statistics) is not built yet")
         if isinstance(batch, DeviceArray):
             batch = batch.tensor
         n = batch.shape[0]
+        if training:
+            # forward on batch statistics, moving averages untouched (no optimisation step)
+            if not isinstance(batch, torch.Tensor):
+                batch = torch.from_numpy(np.ascontiguousarray(np.asarray(batch, dtype=np.float32)))
+            t = self._trainer(n)
+            return DeviceArray(t.forward(batch.to(self.device, torch.float32), momentum_update=False).clone())
         eng = self._engine(n)
         probs = eng.forward(batch)
         return DeviceArray(probs.clone())
@@ -233,10 +237,144 @@ class Model:
         means = totals / count
         return dict(zip(names, map(float, means))) if return_dict else list(map(float, means))
 
-    def fit(self, *args, **kwargs):
-        raise NotImplementedError(
-            "Model.fit is not built yet: the backward kernels (conv dgrad/wgrad, BatchNorm "
-            "batch statistics, loss gradient, Adam) are the next milestone of this package")
+    # ---- training ----------------------------------------------------------------------
+    def _loss_name(self):
+        loss = self.loss if self.loss is not None else LS.cce_dice_loss
+        return loss if isinstance(loss, str) else getattr(loss, "name", getattr(loss, "__name__", str(loss)))
+
+    def _trainer(self, batch):
+        from . import trainer
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        t = getattr(self, "_train_state", None)
+        if t is None or t.n != batch:
+            opt = self.optimizer if self.optimizer is not None else Adam()
+            new = trainer.Trainer(self.graph, self.weights, batch, device=self.device,
+                                  learning_rate=opt.learning_rate, beta_1=opt.beta_1, beta_2=opt.beta_2,
+                                  epsilon=opt.epsilon, loss=self._loss_name(), world_size=world,
+                                  freeze_encoder=self.encoder_freeze)
+            if t is not None:                       # batch size changed: carry the optimiser state over
+                new.load_state(t.state())
+            self._train_state = t = new
+        return t
+
+    @property
+    def is_chief(self):
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+    def train_on_batch(self, x, y, return_dict=True):
+        """One optimisation step on the LOCAL batch of this rank (with torch.distributed
+        initialised: the per-replica batch of a mirrored strategy; gradients are averaged over
+        ranks).  Returns the batch's loss and metrics."""
+        dev = torch.device(self.device)
+
+        def prep(a):
+            if not isinstance(a, torch.Tensor):
+                a = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
+            return a.to(dev, torch.float32).contiguous()
+        x, y = prep(x), prep(y)
+        t = self._trainer(x.shape[0])
+        t.lr = float(self.optimizer.learning_rate) if self.optimizer is not None else t.lr
+        sums, pixels = t.train_step(x, y)
+        s = sums.cpu().numpy().reshape(4, -1)
+        loss = self.loss if (self.loss is not None and not isinstance(self.loss, str)) else \
+            {"categorical_crossentropy": LS.categorical_crossentropy, "dice_loss": LS.dice_loss}.get(
+                self.loss, LS.cce_dice_loss)
+        logs = OrderedDict([("loss", loss.from_sums(s, pixels))])
+        for m in self.metrics:
+            logs[getattr(m, "name", getattr(m, "__name__", str(m)))] = m.from_sums(s, pixels)
+        return logs if return_dict else list(logs.values())
+
+    def sync_from_trainer(self):
+        """Copy the trained parameters (and moving statistics, averaged over ranks) back into
+        `self.weights`, which inference, evaluate() and save() read."""
+        t = getattr(self, "_train_state", None)
+        if t is None:
+            return
+        t.average_moving_stats()
+        self.weights = t.get_weights()
+        self._engines = {}
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None,
+            validation_data=None, steps_per_epoch=None, initial_epoch=0, validation_steps=None,
+            shuffle=True):
+        """Keras-style training loop (the call at model_train.py:284-329).  `x` is an iterable of
+        (images, one-hot masks) batches (a repeating dataset needs steps_per_epoch) or, with `y`,
+        arrays cut into batches of `batch_size`.  With torch.distributed initialised every rank
+        calls fit() on its own shard of the data: one process per GPU, gradients all-reduced on
+        RCCL during the backward pass.  Returns a History."""
+        from . import callbacks as CB
+        if self.optimizer is None:
+            self.compile(optimizer=Adam(), loss=self.loss, metrics=self.metrics)
+        history = CB.History()
+        cbs = list(callbacks or [])
+        for cb in cbs:
+            cb.set_model(self)
+            cb.on_train_begin()
+
+        def batches():
+            if y is not None:
+                n = len(x)
+                bs = batch_size or 32
+                idx = np.random.permutation(n) if shuffle else np.arange(n)
+                for i in range(0, n - bs + 1 if n >= bs else n, bs):
+                    j = idx[i:i + bs]
+                    yield x[j], y[j]
+            else:
+                for b in x:
+                    yield b[0], b[1]
+        it = None
+        for epoch in range(initial_epoch, epochs):
+            for cb in cbs:
+                cb.on_epoch_begin(epoch)
+            if it is None or y is not None:
+                it = iter(batches())
+            totals, count, fresh = OrderedDict(), 0, False
+            while steps_per_epoch is None or count < steps_per_epoch:
+                try:
+                    bx, by = next(it)
+                    fresh = False
+                except StopIteration:
+                    if steps_per_epoch is None or fresh:
+                        it = None               # the epoch is one pass (or the dataset is empty)
+                        break
+                    it, fresh = iter(batches()), True   # a finite dataset is simply walked again
+                    continue
+                logs = self.train_on_batch(bx, by)
+                for k, v in logs.items():
+                    totals[k] = totals.get(k, 0.0) + v
+                count += 1
+            if count == 0:
+                raise ValueError("fit() got an empty dataset")
+            logs = OrderedDict((k, v / count) for k, v in totals.items())
+            self._reduce_logs(logs)
+            self.sync_from_trainer()
+            if validation_data is not None:
+                val = self.evaluate(validation_data, steps=validation_steps)
+                for k, v in val.items():
+                    logs["val_" + k] = v
+            for cb in cbs:
+                cb.on_epoch_end(epoch, logs)
+            history.on_epoch_end(epoch, logs)
+            if verbose and self.is_chief:
+                print("Epoch %d/%d - " % (epoch + 1, epochs) + " - ".join("%s: %.4f" % kv for kv in logs.items()))
+        for cb in cbs:
+            cb.on_train_end()
+        return history
+
+    def _reduce_logs(self, logs):
+        """Average the epoch's training logs over ranks (each rank saw its own shard)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        keys = list(logs)
+        dev = self.device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([logs[k] for k in keys], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        t /= dist.get_world_size()
+        for k, v in zip(keys, t.tolist()):
+            logs[k] = v
 
     # ---- persistence -----------------------------------------------------------------
     def save(self, path):

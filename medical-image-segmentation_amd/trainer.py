@@ -75,7 +75,8 @@ class Seg:
 
 class Trainer:
     def __init__(self, graph, weights, batch, device="cuda:0", learning_rate=1e-3, beta_1=0.9,
-                 beta_2=0.999, epsilon=1e-7, loss="cce_dice", world_size=1, bucket_mb=25):
+                 beta_2=0.999, epsilon=1e-7, loss="cce_dice", world_size=1, bucket_mb=25,
+                 freeze_encoder=False):
         if not torch.cuda.is_available():
             raise L.MisegError("no GPU visible: the HIP training path has no CPU fallback")
         self.lib = L.load()
@@ -92,14 +93,21 @@ class Trainer:
         self.step_count = 0
         self.use_cce = loss in ("cce_dice", "categorical_crossentropy_plus_dice_loss", "cce",
                                 "categorical_crossentropy")
-        self.use_dice = loss in ("cce_dice", "categorical_crossentropy_plus_dice_loss", "dice", "dice_loss")
+        self.use_dice = loss in ("cce_dice", "categorical_crossentropy_plus_dice_loss", "dice_loss")
         if not (self.use_cce or self.use_dice):
             raise NotImplementedError("loss %r is not built on the HIP path" % (loss,))
         self.world = world_size
+        # encoder_freeze (utils/model.py:179,191,203): the backbone's layers keep their weights and
+        # their BatchNormalization layers run on the moving statistics
+        self.frozen = set()
+        if freeze_encoder:
+            for name in graph.layers:
+                self.frozen.add(name)
+                if name == graph.encoder_output:
+                    break
         self.bucket_bytes = int(bucket_mb * 2 ** 20)
         self._analyse()
         self._alloc_params(weights)
-        self._pending = []
         self.keep_grads = False       # debugging: keep (dy, dx) of every layer of the last backward
         self.grad_log = None
 
@@ -173,6 +181,13 @@ class Trainer:
                 self.bn_state[l.name]["ws"] = torch.zeros(2 * cp, dtype=torch.float64, device=dev)
         self.stem_mask = None
         self.set_weights(weights)
+        self.layer_lo = {}
+        for (lname, _), sg in segs.items():
+            self.layer_lo[lname] = min(self.layer_lo.get(lname, sg.off), sg.off)
+        self.buckets = None
+        if self.world > 1:
+            from .shard import GradBuckets
+            self.buckets = GradBuckets(self.G, self.bucket_bytes)
 
     def view(self, layer, wname):
         s = self.segs[(layer, wname)]
@@ -396,6 +411,9 @@ class Trainer:
             if cls == "BatchNormalization" and g.layers[l.inbound[0]].cls == "InputLayer":
                 # bn_data: batch statistics of the fp32 input; applied by the stem's input preparation
                 s = self.bn_state[name]
+                if name in self.frozen:
+                    self._frozen_bn(l, s)
+                    continue
                 mm, mv = self.moving[name] if momentum_update else (None, None)
                 L.check(lib.miseg_input_stats_fwd(
                     self.x_in.data_ptr(), n * self.H * self.W, self.view(name, "beta").data_ptr(),
@@ -441,11 +459,14 @@ class Trainer:
                 c = l.out.c
                 mm, mv = self.moving[name] if momentum_update else (None, None)
                 gamma = self.view(name, "gamma").data_ptr() if l.config["scale"] else None
-                L.check(lib.miseg_bn_stats_fwd(
-                    xin.ptr, xin.pixels, c, xin.pix, gamma, self.view(name, "beta").data_ptr(),
-                    mm.data_ptr() if mm is not None else None, mv.data_ptr() if mv is not None else None,
-                    l.config["momentum"], l.config["epsilon"], s["mean"].data_ptr(), s["var"].data_ptr(),
-                    s["scale"].data_ptr(), s["shift"].data_ptr(), s["ws"].data_ptr(), st))
+                if name in self.frozen:
+                    self._frozen_bn(l, s)
+                else:
+                    L.check(lib.miseg_bn_stats_fwd(
+                        xin.ptr, xin.pixels, c, xin.pix, gamma, self.view(name, "beta").data_ptr(),
+                        mm.data_ptr() if mm is not None else None, mv.data_ptr() if mv is not None else None,
+                        l.config["momentum"], l.config["epsilon"], s["mean"].data_ptr(), s["var"].data_ptr(),
+                        s["scale"].data_ptr(), s["shift"].data_ptr(), s["ws"].data_ptr(), st))
                 cons = self.consumers[name]
                 relu = len(cons) == 1 and g.layers[cons[0]].cls == "Activation" and \
                     g.layers[cons[0]].config["activation"] == "relu"
@@ -499,6 +520,18 @@ class Trainer:
             else:
                 raise NotImplementedError("layer class %s" % cls)
         return self.probs
+
+    def _frozen_bn(self, l, s):
+        """Inference-mode coefficients from the moving statistics."""
+        c = l.out.c
+        mm, mv = self.moving[l.name]
+        scale = torch.rsqrt(mv + l.config["epsilon"])
+        if l.config["scale"]:
+            scale = scale * self.view(l.name, "gamma")
+        s["scale"][:c] = scale
+        s["shift"][:c] = self.view(l.name, "beta") - mm * scale
+        s["mean"][:c] = mm
+        s["var"][:c] = mv
 
     def _stem_forward(self, l, src):
         lib, st, n = self.lib, self.stream(), self.n
@@ -566,7 +599,8 @@ class Trainer:
                                     dz.data_ptr(), n * self.H * self.W, c, 32, loss_scale, temp,
                                     1 if self.use_cce else 0, 1 if self.use_dice else 0, st))
         grads[head.name] = Act(dz, c)
-        bucket_hi = self.nparam
+        if self.buckets is not None:
+            self.buckets.begin()
         for name in reversed(self.order):
             l = g.layers[name]
             cls = l.cls
@@ -582,6 +616,9 @@ class Trainer:
             if cls == "BatchNormalization" and g.layers[l.inbound[0]].cls == "InputLayer":
                 continue                      # bn_data: handled with the stem
             if name not in grads:
+                continue
+            if name in self.frozen:
+                grads.pop(name)               # nothing upstream of a frozen backbone layer learns
                 continue
             dy = grads.pop(name)
             if self.grad_log is not None:
@@ -643,8 +680,9 @@ class Trainer:
                     c0 += ci
             else:
                 raise NotImplementedError("backward of %s" % cls)
-            bucket_hi = self._maybe_allreduce(name, bucket_hi)
-        self._maybe_allreduce(None, bucket_hi, flush=True)
+            self._grads_final(name)
+        if self.buckets is not None:
+            self.buckets.flush()
 
     def _conv_backward(self, l, dy, grads):
         lib, st, n = self.lib, self.stream(), self.n
@@ -726,35 +764,19 @@ class Trainer:
         self._accum(grads, src_name, dx, l.name, dy)
 
     # ------------------------------------------------------------------ data parallel
-    def _maybe_allreduce(self, name, hi, flush=False):
-        """Gradients are produced from the end of the flat buffer towards its start; once the
-        not-yet-reduced tail exceeds the bucket size (or at the end) it is all-reduced on RCCL
-        while the rest of the backward pass keeps running."""
-        if self.world <= 1:
-            return hi
-        import torch.distributed as dist
-        if flush:
-            lo = 0
-        else:
-            l = self.g.layers[name]
-            offs = [s.off for (ln, _), s in self.segs.items() if ln == name]
-            if not offs:
-                return hi
-            lo = min(offs)
-            if (hi - lo) * 4 < self.bucket_bytes:
-                return hi
-        if hi > lo:
-            self._pending.append(dist.all_reduce(self.G[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
-        return lo
-
-    def wait_allreduce(self):
-        for w in self._pending:
-            w.wait()
-        self._pending = []
+    def _grads_final(self, name):
+        """Layer `name`'s parameter gradients are written; everything stored after them in the flat
+        buffer belongs to layers whose backward ran earlier."""
+        if self.buckets is None:
+            return
+        lo = self.layer_lo.get(name)
+        if lo is not None:
+            self.buckets.ready(lo)
 
     # ------------------------------------------------------------------ optimiser
     def adam_step(self):
-        self.wait_allreduce()
+        if self.buckets is not None:
+            self.buckets.wait()
         self.step_count += 1
         t = self.step_count
         lr_t = self.lr * math.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
@@ -762,6 +784,36 @@ class Trainer:
                                          self.G.data_ptr(), self.PB.data_ptr(), self.nparam, lr_t, self.b1,
                                          self.b2, self.eps, 1.0, self.stream()))
         self._dgrad_cache = {}
+
+    # ------------------------------------------------------------------ state
+    def state(self):
+        return {"P": self.P, "M": self.M, "V": self.V, "step": self.step_count, "moving": self.moving}
+
+    def load_state(self, st):
+        self.P.copy_(st["P"])
+        self.M.copy_(st["M"])
+        self.V.copy_(st["V"])
+        self.PB.copy_(self.P)
+        self.step_count = st["step"]
+        for k, (m, v) in st["moving"].items():
+            self.moving[k][0].copy_(m)
+            self.moving[k][1].copy_(v)
+        self._dgrad_cache = {}
+
+    def average_moving_stats(self):
+        """BatchNormalization moving statistics are per replica; a mirrored strategy reads their
+        mean over replicas when the model is saved or evaluated."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        flat = torch.cat([t for pair in self.moving.values() for t in pair])
+        dist.all_reduce(flat)
+        flat /= self.world
+        off = 0
+        for pair in self.moving.values():
+            for t in pair:
+                t.copy_(flat[off:off + t.numel()])
+                off += t.numel()
 
     def train_step(self, x, gt):
         """One optimisation step on a local batch.  Returns (sums, pixels) of the forward pass for

@@ -56,3 +56,58 @@ def test_tile_ranges_match_reference_patch_predict():
     assert shard.tile_ranges(2560, 2560) == [(0, 2560)]
     with pytest.raises(ValueError):
         shard.shard_indices(4, 2, 2)
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import miseg_amd  # noqa: F401
+    from miseg_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 10000
+    flat = torch.zeros(n)
+    b = shard.GradBuckets(flat, bucket_bytes=4 * 3000)
+    launched = []
+    for step in range(2):                          # two backward passes reuse the object
+        flat.zero_()
+        b.begin()
+        # "layers" fill the buffer from the end towards the start, as a backward pass does
+        bounds = [10000, 9000, 8500, 6000, 5900, 2500, 100, 0]
+        for hi, lo in zip(bounds[:-1], bounds[1:]):
+            flat[lo:hi] = torch.arange(lo, hi, dtype=torch.float32) * (rank + 1) + step
+            b.ready(lo)
+        b.flush()
+        b.wait()
+        launched.append(list(b.launched))
+    if rank == 0:
+        torch.save({"flat": flat, "launched": launched}, os.path.join(out_dir, "b.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_two_ranks(tmp_path):
+    """Bucketed gradient all-reduce: every element summed over ranks exactly once, in few large
+    buckets, whatever the layer boundaries."""
+    world = 2
+    mp.spawn(_bucket_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = torch.load(os.path.join(str(tmp_path), "b.pt"))
+    want = torch.arange(10000, dtype=torch.float32) * 3 + 2      # ranks 1x + 2x, step 1 on both
+    assert torch.equal(r["flat"], want)
+    for launched in r["launched"]:
+        assert launched == [(6000, 10000), (2500, 6000), (0, 2500)]
+        covered = sorted(launched)
+        assert covered[0][0] == 0 and covered[-1][1] == 10000
+        assert all(a[1] == b_[0] for a, b_ in zip(covered[:-1], covered[1:]))
+
+
+def test_gradient_buckets_single_process_is_a_no_op():
+    import miseg_amd  # noqa: F401
+    from miseg_amd import shard
+    flat = torch.ones(100)
+    b = shard.GradBuckets(flat, bucket_bytes=64)
+    b.begin()
+    b.ready(50)
+    b.flush()
+    b.wait()
+    assert b.launched == [] and torch.equal(flat, torch.ones(100))

@@ -1,0 +1,136 @@
+"""Model.fit on the HIP path: the surface model_train.py:259-329 uses (History keys, validation,
+ReduceLROnPlateau / ModelCheckpoint, encoder_freeze) and the data-parallel step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _data(n, h, w, c=3, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.random((n, h, w, 3), dtype=np.float32)
+    lab = (x[..., 0] > 0.5).astype(np.int64) + (x[..., 1] > 0.7).astype(np.int64)
+    return x, np.eye(c, dtype=np.float32)[lab]
+
+
+def _batches(x, y, bs):
+    return [(x[i:i + bs], y[i:i + bs]) for i in range(0, len(x), bs)]
+
+
+def test_fit_history_callbacks_and_checkpoint(pkg, tmp_path):
+    sys.path.insert(0, ROOT)
+    from utils import model as um
+    from miseg_amd.callbacks import ModelCheckpoint, ReduceLROnPlateau
+    m = um.make_model("resnet18", "U-Net", (64, 96, 3), 3, 1e-3, um.CUSTOM_OBJECTS[
+        "categorical_crossentropy_plus_dice_loss"], um.METRICS, seed=1)
+    x, y = _data(8, 64, 96)
+    xv, yv = _data(2, 64, 96, seed=9)
+    ckpt = os.path.join(str(tmp_path), "m_e{epoch:03d}_l{loss:.4f}_vl{val_loss:.4f}.h5")
+    cbs = [ReduceLROnPlateau(monitor="val_f1-score", factor=0.1, min_delta=1e-3, min_lr=1e-8, patience=1,
+                             mode="max"),
+           ModelCheckpoint(ckpt, monitor="val_f1-score", mode="max", save_best_only=False)]
+    h = m.fit(_batches(x, y, 2), epochs=3, steps_per_epoch=6, validation_data=_batches(xv, yv, 1),
+              callbacks=cbs, verbose=0)
+    assert set(h.history) == {"loss", "f1-score", "iou_score", "val_loss", "val_f1-score", "val_iou_score", "lr"}
+    assert h.epoch == [0, 1, 2] and all(len(v) == 3 for v in h.history.values())
+    assert h.history["loss"][-1] < h.history["loss"][0]
+    files = sorted(os.listdir(str(tmp_path)))
+    assert len(files) == 3 and files[0].startswith("m_e001_l")
+    # the checkpoint of the last epoch reproduces the validation numbers fit() logged
+    m2 = um.load_model(os.path.join(str(tmp_path), files[-1]), input_shape=(64, 96, 3))
+    m2.compile(loss=m.loss, metrics=m.metrics)
+    ev = m2.evaluate(_batches(xv, yv, 1))
+    assert abs(ev["loss"] - h.history["val_loss"][-1]) < 1e-6
+    assert abs(ev["f1-score"] - h.history["val_f1-score"][-1]) < 1e-6
+    # resume: initial_epoch continues the epoch numbering
+    h2 = m.fit(_batches(x, y, 2), epochs=4, steps_per_epoch=2, initial_epoch=3, verbose=0)
+    assert h2.epoch == [3]
+
+
+def test_encoder_freeze_keeps_backbone(pkg):
+    sys.path.insert(0, ROOT)
+    from utils import model as um
+    m = um.make_model("resnet18", "Linknet", (64, 64, 3), 3, 1e-3, um.CUSTOM_OBJECTS[
+        "categorical_crossentropy_plus_dice_loss"], um.METRICS, encoder_freeze=True, seed=2)
+    before = {k: {n: v.copy() for n, v in d.items()} for k, d in m.weights.items()}
+    x, y = _data(4, 64, 64)
+    m.fit(_batches(x, y, 2), epochs=1, steps_per_epoch=3, verbose=0)
+    g = m.graph
+    names = list(g.layers)
+    enc = set(names[:names.index(g.encoder_output) + 1])
+    changed_dec = 0
+    for k, d in m.weights.items():
+        for n, v in d.items():
+            same = np.array_equal(v, before[k][n])
+            if k in enc:
+                assert same, (k, n)
+            elif n in ("kernel", "gamma", "beta"):
+                changed_dec += (not same)
+    assert changed_dec > 10
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import miseg_amd  # noqa: F401
+    from miseg_amd import netspec, trainer
+    from oracle import nets
+    w = nets.init_weights(nets.build_spec("resnet18", "U-Net", 3), 0, True)
+    g = netspec.build_graph("resnet18", "U-Net", (64, 96, 3), 3, "softmax", None)
+    x, y = _data(2, 64, 96, seed=4)
+    tr = trainer.Trainer(g, w, 1, world_size=world, bucket_mb=8)
+    xd = torch.from_numpy(x[rank:rank + 1]).cuda()
+    yd = torch.from_numpy(y[rank:rank + 1]).cuda()
+    tr.forward(xd)
+    tr.loss_and_metrics(yd)
+    tr.backward(loss_scale=1.0 / world)
+    tr.buckets.wait()
+    torch.cuda.synchronize()
+    torch.save({"G": tr.G.cpu(), "buckets": tr.buckets.launched}, os.path.join(out_dir, "dp%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_two_ranks_one_gpu(pkg, tmp_path):
+    """Two ranks (sharing the one GPU of the test box, gloo staging through the host) each take
+    one image; the all-reduced gradient equals the mean of the two single-rank gradients."""
+    import torch
+    import torch.multiprocessing as mp
+    from miseg_amd import netspec, trainer
+    from oracle import nets
+    world = 2
+    mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "dp0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "dp1.pt"))
+    assert torch.equal(r0["G"], r1["G"])
+    assert len(r0["buckets"]) >= 3                          # several buckets, not one per layer
+    assert sum(hi - lo for lo, hi in r0["buckets"]) == r0["G"].numel()
+    w = nets.init_weights(nets.build_spec("resnet18", "U-Net", 3), 0, True)
+    g = netspec.build_graph("resnet18", "U-Net", (64, 96, 3), 3, "softmax", None)
+    x, y = _data(2, 64, 96, seed=4)
+    tr = trainer.Trainer(g, w, 1)
+    total = None
+    for r in range(world):
+        tr.forward(torch.from_numpy(x[r:r + 1]).cuda(), momentum_update=False)
+        tr.loss_and_metrics(torch.from_numpy(y[r:r + 1]).cuda())
+        tr.backward(loss_scale=1.0 / world)
+        total = tr.G.clone() if total is None else total + tr.G
+    ref = total.cpu()
+    err = float((r0["G"] - ref).norm() / ref.norm())
+    assert err < 1e-3, err            # float atomics in the weight-gradient kernel reorder sums

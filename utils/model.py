@@ -122,7 +122,11 @@ def load_model(model_path, input_shape=None, loss_function=_losses.cce_dice_loss
                optimizer=_DEFAULT_OPTIMIZER, compile=True, use_bias_layer=False):
     if not Path(model_path).is_file():
         raise FileNotFoundError(f"The model file was not found at `{model_path}`.")
-    if str(model_path).endswith(".h5"):
+    # the reference's scripts name every checkpoint *.h5 (model_train.py:187-190), so the format is
+    # told from the file's first bytes: HDF5 (written by Keras) or this package's zip container
+    with open(model_path, "rb") as f:
+        magic = f.read(8)
+    if magic == b"\x89HDF\r\n\x1a\n":
         model = _load_h5(model_path)
     else:
         model = _model.load_container(model_path)
