@@ -64,18 +64,71 @@ def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
                       "(TensorFlow reference not installable offline)" % (n_done, h, w)}
 
 
+def training_leg(args, dev, rank, world, dist, h, w):
+    """Second headline configuration: ResNet-18 U-Net training steps (forward on batch statistics,
+    cce+Dice loss, backward, bucketed gradient all-reduce over RCCL overlapped with the backward
+    pass, Adam) on a fixed synthetic batch per GPU -- the loop behind `model.fit`,
+    /root/reference model_train.py:284-329 with --loss dice (:172-173)."""
+    from miseg_amd import netspec, trainer
+    graph = netspec.build_graph(args.train_encoder, args.decoder, (h, w, 3), args.classes)
+    tr = trainer.Trainer(graph, build_weights(graph), args.train_batch, device=str(dev), loss="cce_dice",
+                         world_size=world)
+    gen = torch.Generator(device=dev).manual_seed(77 + rank)
+    x = torch.rand((args.train_batch, h, w, 3), device=dev, generator=gen)
+    lab = torch.randint(0, args.classes, (args.train_batch, h, w), device=dev, generator=gen)
+    gt = torch.nn.functional.one_hot(lab, args.classes).float()
+    del lab
+    for _ in range(args.train_warmup):
+        tr.train_step(x, gt)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        tr.train_step(x, gt)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    del tr, x, gt
+    torch.cuda.empty_cache()
+    return {"metric": "images/sec at 1920x2560x3 ResNet-18 U-Net training",
+            "value": args.train_batch * world * args.train_steps / elapsed, "unit": "images/s",
+            "ms_per_step": 1e3 * elapsed / args.train_steps, "steps": args.train_steps,
+            "warmup": args.train_warmup, "scaling": "weak",
+            "dtype": "bf16 activations/gradients, fp32 accumulation and master weights",
+            "config": {"workload": "%s %s training %dx%dx3, %d classes, cce+Dice loss, Adam, batch %d "
+                                   "per GPU per step" % (args.train_encoder, args.decoder, h, w,
+                                                         args.classes, args.train_batch),
+                       "parallelism": "data parallel, bucketed RCCL all-reduce overlapped with backward"
+                       if world > 1 else "single GPU"},
+            "peak_hbm_gib": peak}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=1920)
     ap.add_argument("--width", type=int, default=2560)
     ap.add_argument("--encoder", default="resnet34")
     ap.add_argument("--decoder", default="U-Net")
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training leg")
+    ap.add_argument("--train-encoder", default="resnet18")
+    ap.add_argument("--train-batch", type=int, default=16, help="training images per GPU per step")
+    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--train-warmup", type=int, default=1)
     ap.add_argument("--per-op", action="store_true", help="print a per-kernel table to stderr")
     args = ap.parse_args()
 
@@ -128,6 +181,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    train = None
+    if not args.no_train:
+        train = training_leg(args, dev, rank, world, dist, h, w)
 
     result = None
     if rank == 0:
@@ -201,6 +258,8 @@ def main():
                     "non_conv_ms_per_step": float(op_ms[~is_conv].sum())},
             },
         }
+        if train is not None:
+            result["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.encoder, args.decoder, args.classes, h, w, weights)
         print(json.dumps(result), flush=True)

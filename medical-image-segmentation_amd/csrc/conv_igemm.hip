@@ -820,19 +820,15 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
   issue_w(0, 0, 0);
   int chunk = 0, tap = 0, dy = 0, dx = 0;
   for (int s = 0; s < steps; ++s) {
-#ifndef HALO_EXP_NOSYNC
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#endif
     // next step's coordinates
     int ntap = tap + 1, nchk = chunk;
     if (ntap == TAPS) {
       ntap = 0;
       nchk = chunk + 1;
     }
-#ifndef HALO_EXP_NOLOAD
     if (s + 1 < steps) issue_w(ntap, nchk, (s + 1) & 1);
-#endif
     if (HB == 2 && chunk + 1 < nchunk && tap < NHW) {
       // one halo instruction of the next chunk per tap step
 #pragma unroll
