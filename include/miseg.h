@@ -196,6 +196,8 @@ typedef struct miseg_wgrad_desc {
   int64_t x_img;
   int32_t dy_pix, dy_row;
   int64_t dy_img;
+  int32_t tile_hint;   /* 0 = automatic; 1 = per-tap split-K kernel; 2 = halo-resident kernel
+                          (stride 1, square filter up to 3x3, Cin % 32 == 0) */
 } miseg_wgrad_desc;
 int miseg_conv2d_wgrad(const miseg_wgrad_desc* d, void* stream);
 

@@ -15,6 +15,8 @@
 // fp32 gradient with float atomics (two 128-byte row segments per wave instruction).
 #include "common.h"
 
+#include <type_traits>
+
 namespace miseg {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -214,6 +216,194 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Halo-resident weight gradient for stride-1 convolutions with small filters (3x3, the 2x2 phases
+// of Conv2DTranspose, 1x1).  The per-tap kernel above re-reads both operand tiles for every tap;
+// here a block keeps the X halo tile and the dY tile of an 8x32 pixel block in LDS and a wave
+// computes ALL taps of its [32 co] x [32 ci] sub-tile from them: the dY fragment of a pixel run is
+// read once and multiplied with the X fragments of the KH x KW shifted runs, and those stay in
+// registers while the wave walks down the rows (a row of X is used by KH rows of dY).  Blocks are
+// persistent over pixel tiles and flush their accumulators with float atomics once at the end.
+//
+// Waves: 4.  CO_T x CI_T (32 or 64 each) is cut into 32x32 sub-tiles; when there are fewer than 4,
+// the remaining factor splits the pixels (the two 16-pixel column windows, then row halves).
+template <int N, typename F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+  if constexpr (N > 0) {
+    wg_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int KH, int KW, int CO_T, int CI_T>
+__global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradParams p) {
+  constexpr int TH = 8, TW = 32;
+  constexpr int HR = TH + KH - 1, HWD = TW + KW - 1, HP = HR * HWD;
+  constexpr int XRB = CI_T * 2, YRB = CO_T * 2;          // LDS bytes per pixel row
+  constexpr int XPPI = 1024 / XRB, YPPI = 1024 / YRB;    // pixels per wave-instruction
+  constexpr int XLPR = 64 / XPPI, YLPR = 64 / YPPI;      // lanes (16-byte chunks) per pixel
+  constexpr int XNI = (HP + XPPI - 1) / XPPI;            // wave-instructions for the halo
+  constexpr int YNI = TH * TW / YPPI;                    // ... for the dY tile
+  constexpr int XBYTES = XNI * 1024, YBYTES = YNI * 1024;
+  constexpr int WCO = CO_T / 32, WCI = CI_T / 32, WK = 4 / (WCO * WCI);
+  constexpr int TAPS = KH * KW;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[XBYTES + YBYTES];
+  unsigned char* const xt = lds;
+  unsigned char* const yt = lds + XBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = wave % (WCO * WCI);
+  const int wm = q / WCI, wn = q % WCI, kpart = wave / (WCO * WCI);
+
+  const int pair = blockIdx.y;
+  const int co0 = (pair / p.ci_tiles) * CO_T, ci0 = (pair % p.ci_tiles) * CI_T;
+  const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+  const int ntiles = p.N * tiles_y * tiles_x;
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line_wg);
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposing-read geometry (see the per-tap kernel)
+  const int g = lane >> 4;
+  const int kgrp = 8 * (g >> 1) + ((lane & 15) >> 2);
+  const int cgrp = 16 * (g & 1) + 4 * (lane & 3);
+
+  auto xswz = [](int row, int chunk) __attribute__((always_inline)) {
+    return CI_T == 64 ? (chunk ^ (((row >> 1) & 1) << 2)) : chunk;
+  };
+  auto yswz = [](int row, int chunk) __attribute__((always_inline)) {
+    return CO_T == 64 ? (chunk ^ (((row >> 1) & 1) << 2)) : chunk;
+  };
+  auto read2 = [&](const unsigned char* a0, const unsigned char* a1) __attribute__((always_inline)) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto xfrag = [&](int row0) __attribute__((always_inline)) {       // 16 halo pixels from row0
+    const int col = wn * 32 + cgrp, chunk = col >> 3, within = (col & 7) * 2;
+    const int r0 = row0 + kgrp, r1 = r0 + 4;
+    return read2(xt + r0 * XRB + xswz(r0, chunk) * 16 + within,
+                 xt + r1 * XRB + xswz(r1, chunk) * 16 + within);
+  };
+  auto yfrag = [&](int row0) __attribute__((always_inline)) {
+    const int col = wm * 32 + cgrp, chunk = col >> 3, within = (col & 7) * 2;
+    const int r0 = row0 + kgrp, r1 = r0 + 4;
+    return read2(yt + r0 * YRB + yswz(r0, chunk) * 16 + within,
+                 yt + r1 * YRB + yswz(r1, chunk) * 16 + within);
+  };
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int tx = t % tiles_x;
+    t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int n = t / tiles_y;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    __syncthreads();                         // the previous tile's fragments have been read
+    // X halo: LDS pixel hp = hr * HWD + hc  <-  x[n][oy0 + hr - pad_y][ox0 + hc - pad_x]
+#pragma unroll
+    for (int j = 0; j < (XNI + 3) / 4; ++j) {
+      const int inst = j * 4 + wave;
+      if (inst < XNI) {
+        const int hp = inst * XPPI + lane / XLPR, slot = lane % XLPR;
+        const int hr = hp / HWD, hc = hp - hr * HWD;
+        const int iy = oy0 + hr - p.pad_y, ix = ox0 + hc - p.pad_x;
+        const int c = ci0 + xswz(hp, slot) * 8;
+        const bool ok = hp < HP && c < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const bf16_t* src = ok ? p.x + n * p.x_img + (long long)iy * p.x_row + (long long)ix * p.x_pix + c
+                               : zero_src;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(xt + inst * 1024), 16, 0, 0);
+      }
+    }
+    // dY tile: LDS pixel dp = y * TW + x
+#pragma unroll
+    for (int j = 0; j < YNI / 4; ++j) {
+      const int inst = j * 4 + wave;
+      const int dp = inst * YPPI + lane / YLPR, slot = lane % YLPR;
+      const int oy = oy0 + dp / TW, ox = ox0 + dp % TW;
+      const int c = co0 + yswz(dp, slot) * 8;
+      const bool ok = c < p.Cout && oy < p.Ho && ox < p.Wo;
+      const bf16_t* src = ok ? p.dy + n * p.dy_img + (long long)oy * p.dy_row + (long long)ox * p.dy_pix + c
+                             : zero_src;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(yt + inst * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    auto roll = [&](auto rows_c, int w, int ya) __attribute__((always_inline)) {
+      constexpr int ROWS = decltype(rows_c)::value;
+      bf16x8 xf[KH][KW];
+      wg_static_for<ROWS + KH - 1>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;           // halo row ya + i
+        wg_static_for<KW>([&](auto kc) __attribute__((always_inline)) {
+          constexpr int kx = decltype(kc)::value;
+          xf[i % KH][kx] = xfrag((ya + i) * HWD + w * 16 + kx);
+        });
+        if constexpr (i >= KH - 1) {
+          constexpr int y = i - (KH - 1);
+          const bf16x8 yf = yfrag((ya + y) * TW + w * 16);
+          wg_static_for<KH>([&](auto kyc) __attribute__((always_inline)) {
+            constexpr int ky = decltype(kyc)::value;
+            wg_static_for<KW>([&](auto kc) __attribute__((always_inline)) {
+              constexpr int kx = decltype(kc)::value;
+              acc[ky * KW + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                  yf, xf[(y + ky) % KH][kx], acc[ky * KW + kx], 0, 0, 0);
+            });
+          });
+        }
+      });
+    };
+    if constexpr (WK == 1) {
+      roll(std::integral_constant<int, TH>{}, 0, 0);
+      roll(std::integral_constant<int, TH>{}, 1, 0);
+    } else if constexpr (WK == 2) {
+      roll(std::integral_constant<int, TH>{}, kpart, 0);
+    } else {
+      roll(std::integral_constant<int, TH / 2>{}, kpart & 1, (kpart >> 1) * (TH / 2));
+    }
+  }
+
+  const int lcol = lane & 31, lhalf = lane >> 5;
+  const int ci = ci0 + wn * 32 + lcol;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+      if (co < p.Cout && ci < p.Cin)
+        atomicAdd(p.dw + ((long long)co * TAPS + t) * p.Cin + ci, acc[t][r]);
+    }
+}
+
+template <int KH, int KW>
+static void launch_halo_wgrad(const WgradParams& p, hipStream_t stream) {
+  const bool co64 = p.Cout > 32, ci64 = p.Cin > 32;
+  WgradParams q = p;
+  q.co_tiles = co64 ? (p.Cout + 63) / 64 : 1;
+  q.ci_tiles = ci64 ? (p.Cin + 63) / 64 : 1;
+  const int pairs = q.co_tiles * q.ci_tiles;
+  const int ntiles = p.N * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32);
+  int nb = (1024 + pairs - 1) / pairs;                  // ~4 resident blocks per CU over all pairs
+  if (nb > ntiles) nb = ntiles;
+  const dim3 grid((unsigned)nb, (unsigned)pairs);
+  if (co64 && ci64)
+    hipLaunchKernelGGL((wgrad_halo_kernel<KH, KW, 64, 64>), grid, dim3(256), 0, stream, q);
+  else if (co64)
+    hipLaunchKernelGGL((wgrad_halo_kernel<KH, KW, 64, 32>), grid, dim3(256), 0, stream, q);
+  else if (ci64)
+    hipLaunchKernelGGL((wgrad_halo_kernel<KH, KW, 32, 64>), grid, dim3(256), 0, stream, q);
+  else
+    hipLaunchKernelGGL((wgrad_halo_kernel<KH, KW, 32, 32>), grid, dim3(256), 0, stream, q);
+}
+
 int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream) {
   MISEG_CHECK_ARG(d && d->x && d->dy && d->dw, "wgrad: null pointer");
   MISEG_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->Cin > 0 &&
@@ -241,6 +431,24 @@ int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream) {
   p.M = (int)M;
   p.ksteps_total = (p.M + 63) / 64;
   p.taps = d->KH * d->KW;
+  p.co_tiles = p.ci_tiles = 1;
+  p.ksplit = p.ksteps_per_split = 1;
+  const bool halo_shape = d->stride_y == 1 && d->stride_x == 1 && d->KH == d->KW && d->KH <= 3 &&
+                          d->pad_y >= 0 && d->pad_x >= 0 && d->pad_y < d->KH && d->pad_x < d->KW &&
+                          (d->Cin & 31) == 0;
+  const bool want_halo = d->tile_hint == 2 || d->tile_hint == 0;
+  MISEG_CHECK_ARG(d->tile_hint >= 0 && d->tile_hint <= 2, "wgrad: tile_hint must be 0, 1 or 2");
+  if (d->tile_hint == 2 && !halo_shape) {
+    set_error("wgrad: the halo kernel needs stride 1, a square filter up to 3x3 and Cin %% 32 == 0");
+    return MISEG_E_UNSUPPORTED_SHAPE;
+  }
+  if (halo_shape && want_halo) {
+    if (d->KH == 3) launch_halo_wgrad<3, 3>(p, stream);
+    else if (d->KH == 2) launch_halo_wgrad<2, 2>(p, stream);
+    else launch_halo_wgrad<1, 1>(p, stream);
+    MISEG_CHECK_HIP(hipGetLastError());
+    return MISEG_OK;
+  }
   const bool big = d->Cin > 64 && d->Cout > 64;
   const int bc = big ? 128 : 64;
   p.co_tiles = (d->Cout + bc - 1) / bc;

@@ -50,6 +50,7 @@ class WgradDesc(C.Structure):
         ("pad_y", C.c_int32), ("pad_x", C.c_int32),
         ("x_pix", C.c_int32), ("x_row", C.c_int32), ("x_img", C.c_int64),
         ("dy_pix", C.c_int32), ("dy_row", C.c_int32), ("dy_img", C.c_int64),
+        ("tile_hint", C.c_int32),
     ]
 
 

@@ -42,13 +42,28 @@ WG_CASES = [
     (1, 20, 12, 32, 8, 3, 1, 1),
     (3, 8, 8, 256, 128, 4, 2, 1),     # the strided 4x4 conv that is the data gradient of a transpose-conv
     (1, 70, 70, 64, 32, 3, 1, 1),     # several K-steps per split, rows wrapping inside a K-step
+    (2, 17, 45, 32, 32, 3, 1, 1),     # partial pixel tiles in both directions
+    (1, 24, 64, 32, 64, 3, 1, 1),
+    (1, 33, 40, 128, 64, 3, 1, 1),    # two input-channel tiles
+    (1, 16, 32, 96, 160, 3, 1, 1),    # ragged channel tiles
+    (2, 9, 70, 64, 64, 1, 1, 0),
+    (1, 8, 32, 32, 32, 2, 1, 1),
+    (1, 11, 37, 64, 32, 2, 1, 0),
 ]
 
 
+def _halo_ok(case):
+    n, h, w, cin, cout, k, stride, pad = case
+    return stride == 1 and k <= 3 and cin % 32 == 0 and pad < k
+
+
+@pytest.mark.parametrize("hint", [0, 1, 2])
 @pytest.mark.parametrize("case", WG_CASES)
-def test_wgrad(env, case):
+def test_wgrad(env, case, hint):
     L, lib, dev = env
     n, h, w, cin, cout, k, stride, pad = case
+    if hint == 2 and not _halo_ok(case):
+        pytest.skip("shape outside the halo kernel")
     rng = np.random.default_rng(hash(case) % 2**32)
     x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
     ho = (h + 2 * pad - k) // stride + 1
@@ -69,12 +84,14 @@ def test_wgrad(env, case):
     d.pad_y = d.pad_x = pad
     d.x_pix, d.x_row, d.x_img = cin, cin * w, cin * w * h
     d.dy_pix, d.dy_row, d.dy_img = cout, cout * wo, cout * wo * ho
+    d.tile_hint = hint
     L.check(lib.miseg_conv2d_wgrad(C.byref(d), None))
     torch.cuda.synchronize()
     np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
 
 
-def test_wgrad_transpose_conv_phase_views(env):
+@pytest.mark.parametrize("hint", [1, 2])
+def test_wgrad_transpose_conv_phase_views(env, hint):
     """Weight gradient of Conv2DTranspose(4,2,'same'): one call per phase with dy viewed on the
     phase's lattice of the output gradient; result in the forward phase layout."""
     L, lib, dev = env
@@ -100,6 +117,7 @@ def test_wgrad_transpose_conv_phase_views(env):
             d.pad_y, d.pad_x = 1 - a, 1 - b
             d.x_pix, d.x_row, d.x_img = cin, cin * w, cin * w * h
             d.dy_pix, d.dy_row, d.dy_img = 2 * cout, 2 * (2 * w * cout), 4 * h * w * cout
+            d.tile_hint = hint
             L.check(lib.miseg_conv2d_wgrad(C.byref(d), None))
     torch.cuda.synchronize()
     got = dw.cpu().numpy()
