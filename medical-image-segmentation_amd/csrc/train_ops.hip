@@ -6,6 +6,16 @@
 
 namespace miseg {
 
+// Grid of a reduction kernel: every block ends with 2*C global atomics, so blocks must be few and
+// each thread should make at least ~16 trips; 1024 blocks (4 per CU) saturate HBM.
+static inline int reduce_grid(long long pixels, int C8, int block = 256) {
+  long long g = pixels * C8 / (block * 16);
+  if (g > 1024) g = 1024;
+  const int need = (C8 + block - 1) / block;     // at least one thread per channel group
+  if (g < need) g = need;
+  return (int)g;
+}
+
 static inline int grid_cap(long long work, int block = 256, int cap = 2048) {
   long long g = (work + block - 1) / block;
   if (g > cap) g = cap;
@@ -27,17 +37,16 @@ __device__ __forceinline__ uint4 pack8f(const float (&m)[8]) {
 // Work item i = pixel * C8 + c8.  The grid stride is rounded down to a multiple of C8 so a
 // thread keeps one channel group for its whole trip and can accumulate in registers.
 struct ChanWalk {
-  long long first, stride, total;
+  long long pix0, pstep;      // first pixel of this thread and pixels between its visits
   int c8;
   bool active;
   __device__ ChanWalk(long long pixels, int C8) {
     const long long threads = (long long)gridDim.x * blockDim.x;
-    stride = threads / C8 * C8;
+    pstep = threads / C8;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    active = gid < stride;
-    first = gid;
-    total = pixels * C8;
-    c8 = (int)(gid % C8);
+    active = gid < pstep * C8;
+    pix0 = gid / C8;
+    c8 = (int)(gid - pix0 * C8);
   }
 };
 
@@ -69,10 +78,26 @@ __global__ void bn_stats_kernel(const bf16_t* __restrict__ x, long long pixels, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.f;
   if (w.active) {
-    for (long long i = w.first; i < w.total; i += w.stride) {
-      const long long pix = i / C8;
+    const bf16_t* xp = x + w.c8 * 8;
+    long long pix = w.pix0;
+    for (; pix + 3 * w.pstep < pixels; pix += 4 * w.pstep) {
+      uint4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(xp + (pix + u * w.pstep) * ps);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        unpack8f(v, r[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc[0][j] += v[j];
+          acc[1][j] += v[j] * v[j];
+        }
+      }
+    }
+    for (; pix < pixels; pix += w.pstep) {
       float v[8];
-      unpack8f(v, *reinterpret_cast<const uint4*>(x + pix * ps + w.c8 * 8));
+      unpack8f(v, *reinterpret_cast<const uint4*>(xp + pix * ps));
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         acc[0][j] += v[j];
@@ -113,7 +138,7 @@ int launch_bn_stats(const void* x, long long pixels, int C, int ps, const float*
                   "bn_stats: C must be a multiple of 8 (<= 4096), stride a multiple of 8");
   MISEG_CHECK_ARG((mm == nullptr) == (mv == nullptr), "bn_stats: moving stats go together");
   MISEG_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double) * 2 * C, s));
-  const int grid = grid_cap(pixels * (C >> 3));
+  const int grid = reduce_grid(pixels, C >> 3);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(grid), dim3(256), sizeof(double) * 2 * C, s,
                      (const bf16_t*)x, pixels, C, ps, ws);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, pixels, C, gamma,
@@ -179,11 +204,33 @@ __global__ void bn_relu_bwd_reduce_kernel(const bf16_t* __restrict__ x, const bf
       sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c];
       inv[j] = 1.0f / sqrtf(var[c] + eps);
     }
-    for (long long i = w.first; i < w.total; i += w.stride) {
-      const long long pix = i / C8;
+    const bf16_t* xp = x + w.c8 * 8;
+    const bf16_t* dp = dy + w.c8 * 8;
+    long long pix = w.pix0;
+    for (; pix + w.pstep < pixels; pix += 2 * w.pstep) {
+      uint4 rx[2], rg[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        rx[u] = *reinterpret_cast<const uint4*>(xp + (pix + u * w.pstep) * xps);
+        rg[u] = *reinterpret_cast<const uint4*>(dp + (pix + u * w.pstep) * dps);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float xv[8], g[8];
+        unpack8f(xv, rx[u]);
+        unpack8f(g, rg[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float gg = (relu && xv[j] * sc[j] + sh[j] <= 0.f) ? 0.f : g[j];
+          acc[0][j] += gg;
+          acc[1][j] += gg * (xv[j] - mu[j]) * inv[j];
+        }
+      }
+    }
+    for (; pix < pixels; pix += w.pstep) {
       float xv[8], g[8];
-      unpack8f(xv, *reinterpret_cast<const uint4*>(x + pix * xps + w.c8 * 8));
-      unpack8f(g, *reinterpret_cast<const uint4*>(dy + pix * dps + w.c8 * 8));
+      unpack8f(xv, *reinterpret_cast<const uint4*>(xp + pix * xps));
+      unpack8f(g, *reinterpret_cast<const uint4*>(dp + pix * dps));
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float gg = (relu && xv[j] * sc[j] + sh[j] <= 0.f) ? 0.f : g[j];
@@ -215,8 +262,7 @@ __global__ void bn_relu_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf1
     k1[j] = (float)sums[c] * rcount;
     k2[j] = (float)sums[C + c] * rcount;
   }
-  for (long long i = w.first; i < w.total; i += w.stride) {
-    const long long pix = i / C8;
+  for (long long pix = w.pix0; pix < pixels; pix += w.pstep) {
     float xv[8], g[8], o[8];
     unpack8f(xv, *reinterpret_cast<const uint4*>(x + pix * xps + w.c8 * 8));
     unpack8f(g, *reinterpret_cast<const uint4*>(dy + pix * dps + w.c8 * 8));
@@ -245,7 +291,7 @@ int launch_bn_relu_bwd_reduce(const void* x, const void* dy, long long pixels, i
   if (rc) return rc;
   MISEG_CHECK_ARG(scale && shift && mean && var && sums, "bn_relu_bwd_reduce: null pointer");
   MISEG_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, s));
-  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(grid_cap(pixels * (C >> 3))), dim3(256),
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(reduce_grid(pixels, C >> 3)), dim3(256),
                      sizeof(double) * 2 * C, s, (const bf16_t*)x, (const bf16_t*)dy, pixels, C, xps,
                      dps, scale, shift, mean, var, eps, relu, sums);
   MISEG_CHECK_HIP(hipGetLastError());
@@ -277,9 +323,9 @@ __global__ void channel_sums_kernel(const bf16_t* __restrict__ x, long long pixe
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[0][j] = 0.f;
   if (w.active) {
-    for (long long i = w.first; i < w.total; i += w.stride) {
+    for (long long pix = w.pix0; pix < pixels; pix += w.pstep) {
       float v[8];
-      unpack8f(v, *reinterpret_cast<const uint4*>(x + (i / C8) * ps + w.c8 * 8));
+      unpack8f(v, *reinterpret_cast<const uint4*>(x + pix * ps + w.c8 * 8));
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[0][j] += v[j];
     }
@@ -291,7 +337,7 @@ int launch_channel_sums(const void* x, long long pixels, int C, int ps, double* 
   MISEG_CHECK_ARG(x && sums && pixels > 0 && C > 0 && (C & 7) == 0 && (ps & 7) == 0 && C <= 4096,
                   "channel_sums: bad argument");
   MISEG_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * C, s));
-  hipLaunchKernelGGL(channel_sums_kernel, dim3(grid_cap(pixels * (C >> 3))), dim3(256),
+  hipLaunchKernelGGL(channel_sums_kernel, dim3(reduce_grid(pixels, C >> 3)), dim3(256),
                      sizeof(double) * C, s, (const bf16_t*)x, pixels, C, ps, sums);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
@@ -504,11 +550,10 @@ __global__ void copy_channels_kernel(const bf16_t* __restrict__ in, const bf16_t
                                      bf16_t* __restrict__ out, long long pixels, int C, int ips,
                                      int aps, int ops) {
   const int C8 = C >> 3;
-  const long long total = pixels * C8;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c8 = (int)(i % C8);
-    const long long pix = i / C8;
+  ChanWalk w(pixels, C8);
+  if (!w.active) return;
+  const int c8 = w.c8;
+  for (long long pix = w.pix0; pix < pixels; pix += w.pstep) {
     uint4 v = *reinterpret_cast<const uint4*>(in + pix * ips + c8 * 8);
     if (add) {
       float a[8], b[8];
