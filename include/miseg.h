@@ -223,7 +223,9 @@ int miseg_input_stats_fwd(const float* x, int64_t pixels, const float* beta, flo
  * Pass 1 (reduce): g = dy * [x*scale + shift > 0] (relu == 0: g = dy);
  *   sums[c] += sum g, sums[C + c] += sum g * xhat, xhat = (x - mean) * rsqrt(var + eps).
  *   dbeta = sums[0:C], dgamma = sums[C:2C].  sums: double[2*C], zeroed by the call.
- * Pass 2 (apply): dx = scale * (g - sums[c]/pixels - xhat * sums[C+c]/pixels)   (bf16).
+ * Pass 2 (apply): dx = scale * (g - sums[c]/pixels - xhat * sums[C+c]/pixels)   (bf16),
+ *   plus addend[p][c] when addend != NULL: the gradient the layer's input already received from
+ *   its other consumers (a residual branch), so fan-out accumulation costs no extra pass.
  */
 int miseg_bn_relu_bwd_reduce(const void* x, const void* dy, int64_t pixels, int32_t C,
                              int32_t x_pix_stride, int32_t dy_pix_stride, const float* scale,
@@ -233,7 +235,7 @@ int miseg_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, int64_t pix
                             int32_t x_pix_stride, int32_t dy_pix_stride, int32_t dx_pix_stride,
                             const float* scale, const float* shift, const float* mean,
                             const float* var, float eps, int32_t relu, const double* sums,
-                            void* stream);
+                            const void* addend, int32_t addend_pix_stride, void* stream);
 
 /* dx of ZeroPadding2D(1)+MaxPooling2D(3,2): the gradient goes to the first maximum of each
  * window in row-major scan order.  x: pool input [N,H,W,C], dy: [N,H/2,W/2,C], bf16. */

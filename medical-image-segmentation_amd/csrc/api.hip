@@ -41,7 +41,7 @@ int launch_bn_relu_bwd_reduce(const void*, const void*, long long, int, int, int
                               hipStream_t);
 int launch_bn_relu_bwd_apply(const void*, const void*, void*, long long, int, int, int, int,
                              const float*, const float*, const float*, const float*, float, int,
-                             const double*, hipStream_t);
+                             const double*, const void*, int, hipStream_t);
 int launch_channel_sums(const void*, long long, int, int, double*, hipStream_t);
 int launch_maxpool3x3s2_bwd(const void*, const void*, void*, int, int, int, int, int, int, int,
                             hipStream_t);
@@ -190,9 +190,10 @@ int miseg_bn_relu_bwd_reduce(const void* x, const void* dy, int64_t pixels, int3
 int miseg_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, int64_t pixels, int32_t C,
                             int32_t xps, int32_t dps, int32_t ops, const float* scale,
                             const float* shift, const float* mean, const float* var, float eps,
-                            int32_t relu, const double* sums, void* stream) {
+                            int32_t relu, const double* sums, const void* addend,
+                            int32_t addend_pix_stride, void* stream) {
   return launch_bn_relu_bwd_apply(x, dy, dx, pixels, C, xps, dps, ops, scale, shift, mean, var, eps,
-                                  relu, sums, (hipStream_t)stream);
+                                  relu, sums, addend, addend_pix_stride, (hipStream_t)stream);
 }
 int miseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
                            int32_t C, int32_t xps, int32_t dps, int32_t ops, void* stream) {

@@ -248,7 +248,8 @@ __global__ void bn_relu_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf1
                                          const float* __restrict__ shift,
                                          const float* __restrict__ mean,
                                          const float* __restrict__ var, float eps, int relu,
-                                         const double* __restrict__ sums) {
+                                         const double* __restrict__ sums,
+                                         const bf16_t* __restrict__ addend, int aps) {
   const int C8 = C >> 3;
   ChanWalk w(pixels, C8);
   if (!w.active) return;
@@ -271,6 +272,12 @@ __global__ void bn_relu_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf1
       const float gg = (relu && xv[j] * sc[j] + sh[j] <= 0.f) ? 0.f : g[j];
       const float xhat = (xv[j] - mu[j]) * inv[j];
       o[j] = sc[j] * (gg - k1[j] - xhat * k2[j]);
+    }
+    if (addend) {
+      float a[8];
+      unpack8f(a, *reinterpret_cast<const uint4*>(addend + pix * aps + w.c8 * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] += a[j];
     }
     *reinterpret_cast<uint4*>(dx + pix * ops + w.c8 * 8) = pack8f(o);
   }
@@ -301,14 +308,15 @@ int launch_bn_relu_bwd_reduce(const void* x, const void* dy, long long pixels, i
 int launch_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, long long pixels, int C,
                              int xps, int dps, int ops, const float* scale, const float* shift,
                              const float* mean, const float* var, float eps, int relu,
-                             const double* sums, hipStream_t s) {
+                             const double* sums, const void* addend, int aps, hipStream_t s) {
   int rc = check_bn_bwd(x, dy, pixels, C, xps, dps);
   if (rc) return rc;
-  MISEG_CHECK_ARG(dx && scale && shift && mean && var && sums && (ops & 7) == 0,
+  MISEG_CHECK_ARG(dx && scale && shift && mean && var && sums && (ops & 7) == 0 &&
+                      (!addend || ((aps & 7) == 0 && aps >= C)),
                   "bn_relu_bwd_apply: null pointer or bad stride");
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(grid_cap(pixels * (C >> 3), 256, 4096)), dim3(256),
                      0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, pixels, C, xps, dps, ops,
-                     scale, shift, mean, var, eps, relu, sums);
+                     scale, shift, mean, var, eps, relu, sums, (const bf16_t*)addend, aps);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
 }

@@ -77,7 +77,7 @@ SIGNATURES = {
     "miseg_bn_relu_bwd_reduce": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, _FP, _FP, _FP, _FP,
                                            C.c_float, _I32, _VP, _VP]),
     "miseg_bn_relu_bwd_apply": (C.c_int, [_VP, _VP, _VP, _I64, _I32, _I32, _I32, _I32, _FP, _FP, _FP,
-                                          _FP, C.c_float, _I32, _VP, _VP]),
+                                          _FP, C.c_float, _I32, _VP, _VP, _I32, _VP]),
     "miseg_maxpool3x3s2_bwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_avgpool2x2_bwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_upsample_nearest_bwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),

@@ -119,6 +119,21 @@ class Trainer:
             for i in l.inbound:
                 self.consumers[i].append(l.name)
         self.order = list(g.layers)
+        # Concatenate without copies: a tensor that feeds a Concatenate is produced directly inside
+        # the concatenated buffer (every kernel writes through a pixel stride), nested concatenations
+        # (DenseNet blocks) share the outermost buffer.  place[tensor] = (concat layer, channel offset)
+        self.place = {}
+        for l in g.layers.values():
+            if l.cls != "Concatenate":
+                continue
+            chans = [g.layers[i].out.c for i in l.inbound]
+            if any(c % 32 for c in chans):
+                continue
+            c0 = 0
+            for i, c in zip(l.inbound, chans):
+                if i not in self.place and g.layers[i].cls not in ("InputLayer", "ZeroPadding2D"):
+                    self.place[i] = (l.name, c0)
+                c0 += c
 
     def _src(self, name):
         """Skip ZeroPadding2D: returns (producer layer name, accumulated padding)."""
@@ -290,8 +305,22 @@ class Trainer:
             t = torch.empty((self.n, h, w, cp), dtype=torch.bfloat16, device=self.dev)
         return Act(t, c)
 
+    def new_out(self, key, h, w, c):
+        """Output tensor of layer `key`: a slice of the concatenated buffer it feeds, if any."""
+        c0, root = 0, key
+        while root in self.place:
+            root, off = self.place[root]
+            c0 += off
+        if self.g.layers[root].cls != "Concatenate":
+            return self.new(h, w, c)
+        buf = self.concat_bufs.get(root)
+        if buf is None:
+            rl = self.g.layers[root].out
+            buf = self.concat_bufs[root] = self.new(rl.h, rl.w, rl.c)
+        return buf.slice(c0, c)
+
     def conv(self, x, wptr, cout, kh, kw, sy, sx, py, px, out, ho, wo, bias=None, transposed=False,
-             out_view=None, act=L.ACT_NONE, probs=None, temperature=1.0):
+             out_view=None, act=L.ACT_NONE, probs=None, temperature=1.0, residual=None):
         """out_view: (ptr, pix, row, img) to address a strided lattice; default = dense `out`."""
         d = L.ConvDesc()
         d.inp, d.weight = x.ptr, wptr
@@ -313,6 +342,10 @@ class Trainer:
             d.out = out.ptr
             d.out_pix_stride, d.out_row_stride, d.out_img_stride = out.pix, out.pix * ow, out.pix * ow * oh
         d.shift = bias
+        if residual is not None:
+            r = residual
+            d.residual, d.res_dtype = r.ptr, L.DT_BF16
+            d.res_pix_stride, d.res_row_stride, d.res_img_stride = r.pix, r.pix * r.w, r.pix * r.w * r.h
         d.act = act
         d.transposed = 1 if transposed else 0
         d.temperature = temperature
@@ -332,10 +365,11 @@ class Trainer:
         d.dy_pix, d.dy_row, d.dy_img = dy_strides
         L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.stream()))
 
-    def add_into(self, a, b, c=None):
-        """returns a + b (bf16) as a new tensor."""
+    def add_into(self, a, b, c=None, out=None):
+        """returns a + b (bf16) as a new tensor (or in `out`)."""
         c = c or a.c
-        out = self.new(a.h, a.w, c)
+        if out is None:
+            out = self.new(a.h, a.w, c)
         L.check(self.lib.miseg_copy_channels(a.ptr, b.ptr, out.ptr, a.pixels, c, a.pix, b.pix, out.pix,
                                              self.stream()))
         return out
@@ -401,6 +435,7 @@ class Trainer:
         g, lib, st = self.g, self.lib, self.stream()
         self.acts = {}
         self.saved = {}
+        self.concat_bufs = {}
         n = self.n
         self.x_in = x.contiguous()
         for name in self.order:
@@ -433,7 +468,6 @@ class Trainer:
                     self._stem_forward(l, src)
                     continue
                 xin = self.acts[src]
-                out = self.new(l.out.h, l.out.w, co)
                 if name == g.logits_layer:
                     probs = torch.empty((n, l.out.h, l.out.w, co), dtype=torch.float32, device=self.dev)
                     act = L.ACT_SIGMOID if g.activation == "sigmoid" else L.ACT_SOFTMAX
@@ -443,13 +477,14 @@ class Trainer:
                     self.probs = probs
                     self.saved[name] = (xin, pad)
                     continue
+                out = self.new_out(name, l.out.h, l.out.w, co)
                 self.conv(xin, self.wptr(name), co, k, k, stride, stride, pad, pad, out, l.out.h, l.out.w,
                           bias=bias)
                 self.acts[name] = out
                 self.saved[name] = (xin, pad)
             elif cls == "Conv2DTranspose":
                 xin = self.acts[l.inbound[0]]
-                out = self.new(l.out.h, l.out.w, l.out.c)
+                out = self.new_out(name, l.out.h, l.out.w, l.out.c)
                 self.conv(xin, self.wptr(name), l.out.c, 2, 2, 1, 1, 0, 0, out, xin.h, xin.w, transposed=True)
                 self.acts[name] = out
                 self.saved[name] = (xin, 0)
@@ -472,7 +507,7 @@ class Trainer:
                     g.layers[cons[0]].config["activation"] == "relu"
                 if not relu:
                     raise NotImplementedError("BatchNormalization without a following ReLU: %s" % name)
-                out = self.new(xin.h, xin.w, c)
+                out = self.new_out(cons[0], xin.h, xin.w, c)
                 L.check(lib.miseg_scale_shift_relu_fwd(xin.ptr, out.ptr, s["scale"].data_ptr(),
                                                        s["shift"].data_ptr(), xin.pixels, c, xin.pix,
                                                        out.pix, st))
@@ -485,19 +520,19 @@ class Trainer:
             elif cls == "MaxPooling2D":
                 src, _ = self._src(l.inbound[0])
                 xin = self.acts[src]
-                out = self.new(l.out.h, l.out.w, l.out.c)
+                out = self.new_out(name, l.out.h, l.out.w, l.out.c)
                 L.check(lib.miseg_maxpool3x3s2_fwd(xin.ptr, out.ptr, None, None, n, xin.h, xin.w, xin.c,
                                                    xin.pix, out.pix, st))
                 self.acts[name] = out
                 self.saved[name] = xin
             elif cls == "AveragePooling2D":
                 xin = self.acts[l.inbound[0]]
-                out = self.new(l.out.h, l.out.w, l.out.c)
+                out = self.new_out(name, l.out.h, l.out.w, l.out.c)
                 L.check(lib.miseg_avgpool2x2_fwd(xin.ptr, out.ptr, n, xin.h, xin.w, xin.c, xin.pix, out.pix, st))
                 self.acts[name] = out
             elif cls == "UpSampling2D":
                 xin = self.acts[l.inbound[0]]
-                out = self.new(l.out.h, l.out.w, l.out.c)
+                out = self.new_out(name, l.out.h, l.out.w, l.out.c)
                 if l.config["interpolation"] == "bilinear":
                     L.check(lib.miseg_upsample_bilinear2x_fwd(xin.ptr, out.ptr, n, xin.h, xin.w, xin.c,
                                                               xin.pix, out.pix, st))
@@ -508,13 +543,14 @@ class Trainer:
                 self.acts[name] = out
             elif cls == "Add":
                 a, b = self.acts[l.inbound[0]], self.acts[l.inbound[1]]
-                self.acts[name] = self.add_into(a, b, l.out.c)
+                self.acts[name] = self.add_into(a, b, l.out.c, out=self.new_out(name, l.out.h, l.out.w, l.out.c))
             elif cls == "Concatenate":
-                out = self.new(l.out.h, l.out.w, l.out.c)
+                out = self.new_out(name, l.out.h, l.out.w, l.out.c)
                 c0 = 0
                 for i in l.inbound:
                     src = self.acts[i]
-                    self.copy(src, out.slice(c0, src.c), src.c)
+                    if self.place.get(i) != (name, c0):          # not produced in place
+                        self.copy(src, out.slice(c0, src.c), src.c)
                     c0 += src.c
                 self.acts[name] = out
             else:
@@ -549,7 +585,7 @@ class Trainer:
         # channel 3 = indicator of "inside the image": the stem's weight gradient for that (dead)
         # channel then equals the per-tap sums of dY that the input BatchNorm's beta gradient needs
         padded[:, 3:3 + h, 3:3 + w, 3] = 1.0
-        out = self.new(h // 2, w // 2, 64)
+        out = self.new_out(l.name, h // 2, w // 2, 64)
         d = L.ConvDesc()
         d.inp, d.weight = padded.data_ptr(), self.wptr(l.name)
         d.N, d.H, d.W, d.Cin = n, h + 6, w // 2, 32
@@ -575,6 +611,19 @@ class Trainer:
         return self.loss_sums, pixels
 
     # ------------------------------------------------------------------ backward
+    def _fused_dgrad(self, grads, src_name, producer, dy, run):
+        """Data gradient of a convolution accumulated onto the gradient its input already holds:
+        `run(residual)` launches the convolution with that gradient as the epilogue's residual."""
+        res = grads.pop(src_name, None)
+        if res is None:
+            self._accum(grads, src_name, run(None), producer, dy)
+            return
+        if self.grad_log is not None:            # checks want the un-accumulated part as well
+            part = run(None)
+            self.grad_log[producer] = (dy, part)
+            self.accum_log.setdefault(src_name, []).append(part)
+        grads[src_name] = run(res)
+
     def _accum(self, grads, name, gact, producer=None, dy=None):
         if self.grad_log is not None:
             if producer is not None:
@@ -636,15 +685,18 @@ class Trainer:
                                                      s["scale"].data_ptr(), s["shift"].data_ptr(),
                                                      s["mean"].data_ptr(), s["var"].data_ptr(),
                                                      l.config["epsilon"], 1, sums.data_ptr(), st))
-                dx = self.new(xin.h, xin.w, cc)
-                L.check(lib.miseg_bn_relu_bwd_apply(xin.ptr, dy.ptr, dx.ptr, xin.pixels, cc, xin.pix, dy.pix,
-                                                    dx.pix, s["scale"].data_ptr(), s["shift"].data_ptr(),
-                                                    s["mean"].data_ptr(), s["var"].data_ptr(),
-                                                    l.config["epsilon"], 1, sums.data_ptr(), st))
+                def run(res, xin=xin, s=s, cc=cc, sums=sums, dy=dy, eps=l.config["epsilon"]):
+                    out = self.new(xin.h, xin.w, cc)
+                    L.check(lib.miseg_bn_relu_bwd_apply(
+                        xin.ptr, dy.ptr, out.ptr, xin.pixels, cc, xin.pix, dy.pix, out.pix,
+                        s["scale"].data_ptr(), s["shift"].data_ptr(), s["mean"].data_ptr(),
+                        s["var"].data_ptr(), eps, 1, sums.data_ptr(), res.ptr if res is not None else None,
+                        res.pix if res is not None else 0, st))
+                    return out
                 self.gview(name, "beta").copy_(sums[:cc])
                 if l.config["scale"]:
                     self.gview(name, "gamma").copy_(sums[cc:])
-                self._accum(grads, l.inbound[0], dx, name, dy)
+                self._fused_dgrad(grads, l.inbound[0], name, dy, run)
             elif cls == "MaxPooling2D":
                 xin = self.saved[name]
                 dx = self.new(xin.h, xin.w, xin.c)
@@ -674,8 +726,11 @@ class Trainer:
                 c0 = 0
                 for i in l.inbound:
                     ci = g.layers[i].out.c
-                    part = self.new(dy.h, dy.w, ci)
-                    self.copy(dy.slice(c0, ci), part, ci)
+                    if ci % 32 == 0 and (dy.c0 + c0) % 8 == 0:
+                        part = dy.slice(c0, ci)                   # consumers read through the stride
+                    else:
+                        part = self.new(dy.h, dy.w, ci)
+                        self.copy(dy.slice(c0, ci), part, ci)
                     self._accum(grads, i, part)
                     c0 += ci
             else:
@@ -725,12 +780,18 @@ class Trainer:
         if self.g.layers[src_name].cls == "InputLayer":
             return
         ci = xin.c
-        dx = self.new(xin.h, xin.w, ci, zero=(stride != 1))
         packs = self.dgrad_weight(l)
-        dyv = Act(dy.t, cop)
+        dyv = Act(dy.t, cop, dy.c0)
         if stride == 1:
-            self.conv(dyv, packs[0].data_ptr(), ci, k, k, 1, 1, pad, pad, dx, xin.h, xin.w)
+            def run(res):
+                out = self.new(xin.h, xin.w, ci)
+                self.conv(dyv, packs[0].data_ptr(), ci, k, k, 1, 1, k - 1 - pad, k - 1 - pad, out, xin.h,
+                          xin.w, residual=res)
+                return out
+            self._fused_dgrad(grads, src_name, l.name, dy, run)
+            return
         else:
+            dx = self.new(xin.h, xin.w, ci, zero=True)
             for ph, pk in enumerate(packs):
                 if pk is None:
                     continue
@@ -757,11 +818,14 @@ class Trainer:
                            self.G.data_ptr() + 4 * (seg.off + (a * 2 + b) * per_phase), cin, co, 2, 2, 1, 1,
                            1 - a, 1 - b, xin.h, xin.w)
         src_name = l.inbound[0]
-        dx = self.new(xin.h, xin.w, xin.c)
         wt = self.dgrad_weight(l)[0]
-        dyv = Act(dy.t, _c32(co))
-        self.conv(dyv, wt.data_ptr(), xin.c, 4, 4, 2, 2, 1, 1, dx, xin.h, xin.w)
-        self._accum(grads, src_name, dx, l.name, dy)
+        dyv = Act(dy.t, _c32(co), dy.c0)
+
+        def run(res):
+            out = self.new(xin.h, xin.w, xin.c)
+            self.conv(dyv, wt.data_ptr(), xin.c, 4, 4, 2, 2, 1, 1, out, xin.h, xin.w, residual=res)
+            return out
+        self._fused_dgrad(grads, src_name, l.name, dy, run)
 
     # ------------------------------------------------------------------ data parallel
     def _grads_final(self, name):

@@ -172,8 +172,16 @@ def test_bn_stats_and_backward(env):
     dx = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device=dev)
     L.check(lib.miseg_bn_relu_bwd_apply(xptr, dyd.data_ptr(), dx.data_ptr(), pixels, c, c + extra, c, c,
                                         scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), var.data_ptr(),
-                                        eps, 1, sums.data_ptr(), None))
+                                        eps, 1, sums.data_ptr(), None, 0, None))
+    # the same with a gradient that is already there added in (fan-out of the layer's input)
+    other = dbf(bf16_round(rng.normal(0, 1, (n, h, w, c))), dev)
+    dx2 = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_bn_relu_bwd_apply(xptr, dyd.data_ptr(), dx2.data_ptr(), pixels, c, c + extra, c, c,
+                                        scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), var.data_ptr(),
+                                        eps, 1, sums.data_ptr(), other.data_ptr(), c, None))
     torch.cuda.synchronize()
+    np.testing.assert_allclose(dx2.float().cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy()
+                               + other.float().cpu().numpy(), rtol=2e-2, atol=2e-2)
     s = sums.cpu().numpy()
     np.testing.assert_allclose(s[:c], bt_.grad.numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(s[c:], gt_.grad.numpy(), rtol=1e-4, atol=1e-3)
