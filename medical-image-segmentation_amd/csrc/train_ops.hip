@@ -352,61 +352,91 @@ int launch_channel_sums(const void* x, long long pixels, int C, int ps, double* 
 }
 
 // ------------------------------------------------------------------ pooling / upsampling backward
-__global__ void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+// One thread owns a 2x2 block of input pixels (rows 2a, 2a+1; columns 2b, 2b+1) and 8 channels.
+// The windows that can route a gradient into the block are (a..a+1) x (b..b+1); together they
+// cover the 5x5 patch of rows 2a-1..2a+3, which is loaded once.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                         bf16_t* __restrict__ dx, int N, int H, int W, int C, int xps,
                                         int dps, int ops) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, C8 = C >> 3;
-  const long long total = (long long)N * H * W * C8;
+  const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+  const long long total = (long long)N * Hb * Wb * C8;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c8 = (int)(i % C8);
     long long r = i / C8;
-    const int ix = (int)(r % W);
-    r /= W;
-    const int iy = (int)(r % H);
-    const int n = (int)(r / H);
+    const int bx = (int)(r % Wb);
+    r /= Wb;
+    const int by = (int)(r % Hb);
+    const int n = (int)(r / Hb);
     const bf16_t* xb = x + (long long)n * H * W * xps + c8 * 8;
-    float acc[8];
+    uint4 patch[5][5];                                            // bf16x8 per pixel
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    // windows (oy, ox) that contain (iy, ix): window oy covers rows 2oy-1 .. 2oy+1
-    const int oy_lo = iy / 2, oy_hi = (iy + 1) / 2;       // iy odd: two windows, even: one
-    const int ox_lo = ix / 2, ox_hi = (ix + 1) / 2;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      if (oy >= Ho) continue;
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        if (ox >= Wo) continue;
-        // first maximum of the window in row-major order; padded positions hold 0
+    for (int py = 0; py < 5; ++py) {
+      const int y = 2 * by - 1 + py;
+#pragma unroll
+      for (int px = 0; px < 5; ++px) {
+        const int xx = 2 * bx - 1 + px;
+        patch[py][px] = ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
+                            ? *reinterpret_cast<const uint4*>(xb + ((long long)y * W + xx) * xps)
+                            : make_uint4(0, 0, 0, 0);             // ZeroPadding2D
+      }
+    }
+    float acc[2][2][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[q >> 1][q & 1][j] = 0.f;
+#pragma unroll
+    for (int wy = 0; wy < 2; ++wy) {
+      const int oy = by + wy;
+#pragma unroll
+      for (int wx = 0; wx < 2; ++wx) {
+        const int ox = bx + wx;
+        const bool live = oy < Ho && ox < Wo;
+        float g[8];
+        unpack8f(g, live ? *reinterpret_cast<const uint4*>(
+                               dy + (((long long)n * Ho + oy) * Wo + ox) * dps + c8 * 8)
+                         : make_uint4(0, 0, 0, 0));
+        // first maximum of the window in row-major order
         float best[8];
         int bidx[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { best[j] = -3.0e38f; bidx[j] = -1; }
-        for (int dy_ = 0; dy_ < 3; ++dy_) {
-          const int y = 2 * oy - 1 + dy_;
-          for (int dx_ = 0; dx_ < 3; ++dx_) {
-            const int xx = 2 * ox - 1 + dx_;
-            float v[8];
-            if ((unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W) {
-              unpack8f(v, *reinterpret_cast<const uint4*>(xb + ((long long)y * W + xx) * xps));
-            } else {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = 0.f;
-            }
+        for (int dy_ = 0; dy_ < 3; ++dy_)
+#pragma unroll
+          for (int dx_ = 0; dx_ < 3; ++dx_) {
+            float v[8];
+            unpack8f(v, patch[2 * wy + dy_][2 * wx + dx_]);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
               if (v[j] > best[j]) { best[j] = v[j]; bidx[j] = dy_ * 3 + dx_; }
           }
-        }
-        const int my = (iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1));
-        float g[8];
-        unpack8f(g, *reinterpret_cast<const uint4*>(
-                        dy + (((long long)n * Ho + oy) * Wo + ox) * dps + c8 * 8));
+        // block pixel (qy, qx) sits at patch (1+qy, 1+qx) = window position (1+qy-2wy, 1+qx-2wx)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (bidx[j] == my) acc[j] += g[j];
+        for (int qy = 0; qy < 2; ++qy) {
+          const int ry = 1 + qy - 2 * wy;
+#pragma unroll
+          for (int qx = 0; qx < 2; ++qx) {
+            const int rx = 1 + qx - 2 * wx;
+            if (ry >= 0 && ry <= 2 && rx >= 0 && rx <= 2) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (bidx[j] == ry * 3 + rx) acc[qy][qx][j] += g[j];
+            }
+          }
+        }
       }
     }
-    *reinterpret_cast<uint4*>(dx + (((long long)n * H + iy) * W + ix) * ops + c8 * 8) = pack8f(acc);
+#pragma unroll
+    for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+      for (int qx = 0; qx < 2; ++qx) {
+        const int iy = 2 * by + qy, ix = 2 * bx + qx;
+        if (iy < H && ix < W)
+          *reinterpret_cast<uint4*>(dx + (((long long)n * H + iy) * W + ix) * ops + c8 * 8) = pack8f(acc[qy][qx]);
+      }
   }
 }
 
@@ -416,8 +446,8 @@ int launch_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int 
   MISEG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (xps & 7) == 0 &&
                       (dps & 7) == 0 && (ops & 7) == 0,
                   "maxpool_bwd: C and strides must be multiples of 8");
-  const long long total = (long long)N * H * W * (C >> 3);
-  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_cap(total, 256, 8192)), dim3(256), 0, s,
+  const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C >> 3);
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_cap(total, 256, 16384)), dim3(256), 0, s,
                      (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, xps, dps, ops);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;

@@ -236,7 +236,7 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
 }
 
 template <int KH, int KW, int CO_T, int CI_T>
-__global__ __launch_bounds__(256) void wgrad_halo_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, (KH * KW == 9 && CO_T == 64 && CI_T == 64) ? 1 : 2) void wgrad_halo_kernel(const WgradParams p) {
   constexpr int TH = 8, TW = 32;
   constexpr int HR = TH + KH - 1, HWD = TW + KW - 1, HP = HR * HWD;
   constexpr int XRB = CI_T * 2, YRB = CO_T * 2;          // LDS bytes per pixel row
