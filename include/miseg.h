@@ -268,7 +268,9 @@ int miseg_channel_sums(const void* x, int64_t pixels, int32_t C, int32_t pix_str
  *   g_c  = d loss / d pr_c  (cross-entropy term masked where clip(pr) saturates; Dice term
  *          from the per-class sums that miseg_loss_sums produced over the same tensors)
  *   dz_c = pr_c * (g_c - sum_j g_j pr_j) / temperature
- * gt, pr: fp32 [pixels][C]; dlogits: bf16 [pixels][out_stride] (channels >= C left untouched).
+ * gt, pr: fp32 [pixels][C]; dlogits: bf16 [pixels][out_stride]; when
+ * out_stride is a multiple of 8 the channels >= C are written as zeros (the zero padding the
+ * convolutions that consume it expect), otherwise they are left untouched.
  * use_cce / use_dice select the terms.
  */
 int miseg_loss_grad(const float* gt, const float* pr, const double* sums, void* dlogits,

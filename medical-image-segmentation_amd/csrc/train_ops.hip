@@ -654,9 +654,19 @@ __global__ void loss_grad_kernel(const float* __restrict__ gt, const float* __re
       g[c] = gc * loss_scale;
       dot += g[c] * p[c];
     }
+    if ((out_stride & 7) == 0) {
+      // whole line in 16-byte stores: the C gradients, then zeros up to out_stride
+      float o[8];
 #pragma unroll
-    for (int c = 0; c < C; ++c)
-      dz[i * out_stride + c] = f32_to_bf16(p[c] * (g[c] - dot) * inv_temperature);
+      for (int c = 0; c < 8; ++c) o[c] = c < C ? p[c < C ? c : 0] * (g[c < C ? c : 0] - dot) * inv_temperature : 0.f;
+      uint4* line = reinterpret_cast<uint4*>(dz + i * out_stride);
+      line[0] = pack8f(o);
+      for (int k = 1; k < (out_stride >> 3); ++k) line[k] = make_uint4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+        dz[i * out_stride + c] = f32_to_bf16(p[c] * (g[c] - dot) * inv_temperature);
+    }
   }
 }
 

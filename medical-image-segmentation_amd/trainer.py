@@ -642,7 +642,7 @@ class Trainer:
         self.accum_log, self.accum_final = {}, {}
         c = self.classes
         head = g.layers[g.logits_layer]
-        dz = torch.zeros((n, self.H, self.W, 32), dtype=torch.bfloat16, device=self.dev)
+        dz = torch.empty((n, self.H, self.W, 32), dtype=torch.bfloat16, device=self.dev)   # the kernel zero-pads
         temp = g.temperature if g.temperature else 1.0
         L.check(lib.miseg_loss_grad(self.gt.data_ptr(), self.probs.data_ptr(), self.loss_sums.data_ptr(),
                                     dz.data_ptr(), n * self.H * self.W, c, 32, loss_scale, temp,

@@ -271,14 +271,17 @@ def test_loss_grad_matches_autograd(env, classes, temp):
     prd, gtd = df32(pr.detach().numpy(), dev), df32(gt, dev)
     sums = torch.zeros(4 * classes, dtype=torch.float64, device=dev)
     L.check(lib.miseg_loss_sums(gtd.data_ptr(), prd.data_ptr(), sums.data_ptr(), n * h * w, classes, None))
-    dz = torch.zeros((n, h, w, 8), dtype=torch.bfloat16, device=dev)
-    L.check(lib.miseg_loss_grad(gtd.data_ptr(), prd.data_ptr(), sums.data_ptr(), dz.data_ptr(), n * h * w,
-                                classes, 8, 0.5, temp, 1, 1, None))
-    torch.cuda.synchronize()
-    got = dz.float().cpu().numpy()
     want = zt.grad.numpy()
-    np.testing.assert_allclose(got[..., :classes], want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
-    assert np.all(got[..., classes:] == 0)
+    for stride in (8, 32, 5):          # multiples of 8: padding channels are zeroed by the kernel
+        dz = torch.full((n, h, w, stride), 7.0, dtype=torch.bfloat16, device=dev)
+        if stride < classes:
+            continue
+        L.check(lib.miseg_loss_grad(gtd.data_ptr(), prd.data_ptr(), sums.data_ptr(), dz.data_ptr(), n * h * w,
+                                    classes, stride, 0.5, temp, 1, 1, None))
+        torch.cuda.synchronize()
+        got = dz.float().cpu().numpy()
+        np.testing.assert_allclose(got[..., :classes], want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
+        assert np.all(got[..., classes:] == (0 if stride % 8 == 0 else 7.0))
 
 
 def test_adam_keras_form(env):
