@@ -293,8 +293,10 @@ class Model:
         if t is None:
             return
         t.average_moving_stats()
-        self.weights = t.get_weights()
-        self._engines = {}
+        if getattr(t, "dirty", True):
+            self.weights = t.get_weights()
+            self._engines = {}
+            t.dirty = False
 
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, callbacks=None,
             validation_data=None, steps_per_epoch=None, initial_epoch=0, validation_steps=None,
@@ -378,9 +380,15 @@ class Model:
 
     # ---- persistence -----------------------------------------------------------------
     def save(self, path):
-        """Single-file container (numpy .npz): the JSON config plus every weight
-        under '<layer>/<weight>:0', the key an .h5 written by Keras uses inside
-        'model_weights'.  Written atomically."""
+        """`*.h5` / `*.hdf5`: a Keras HDF5 model file (keras_h5.save_keras_h5), which is what the
+        reference's ModelCheckpoint writes (model_train.py:187-190,262).  Any other name: a
+        single-file numpy container (.npz layout): the JSON config plus every weight under
+        '<layer>/<weight>:0'.  Both are written atomically and read back by `load_model`."""
+        self.sync_from_trainer()
+        if str(path).endswith((".h5", ".hdf5")):
+            from . import keras_h5
+            keras_h5.save_keras_h5(self, path)
+            return
         arrays = {"__config__": np.frombuffer(self.to_json().encode(), dtype=np.uint8),
                   "__version__": np.asarray([CONTAINER_VERSION])}
         for l, w, _, _ in self.graph.weight_spec():

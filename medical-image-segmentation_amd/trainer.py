@@ -848,6 +848,7 @@ class Trainer:
                                          self.G.data_ptr(), self.PB.data_ptr(), self.nparam, lr_t, self.b1,
                                          self.b2, self.eps, 1.0, self.stream()))
         self._dgrad_cache = {}
+        self.dirty = True                 # host copies of the weights are stale
 
     # ------------------------------------------------------------------ state
     def state(self):

@@ -8,8 +8,8 @@ segmentation_models.
 Differences a caller can observe:
   * encoder weights are Keras-initialised from a seed (the reference asks
     segmentation_models for `encoder_weights="imagenet"`, a download);
-  * model files are single-file `.npz` containers written by `Model.save`;
-    a Keras `.h5` is read when `h5py` is importable;
+  * model files: Keras HDF5 (`*.h5`) is read and written by this package's own
+    pure-Python HDF5 code (no h5py); other names give a single-file `.npz` container;
   * the PSPNet decoder and the PapBias layer are not provided.
 """
 import os
@@ -109,13 +109,8 @@ def make_model(encoder, decoder, input_shape, classes, learning_rate, loss_funct
 
 
 def _load_h5(model_path):
-    try:
-        import h5py  # noqa: F401
-    except ImportError as e:
-        raise ImportError("reading a Keras .h5 needs h5py, which is not installed here; "
-                          "convert the file to the .npz container with Model.save") from e
-    from miseg_amd import h5io
-    return h5io.load_keras_h5(model_path)
+    from miseg_amd import keras_h5
+    return keras_h5.load_keras_h5(model_path)
 
 
 def load_model(model_path, input_shape=None, loss_function=_losses.cce_dice_loss,
