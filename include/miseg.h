@@ -285,6 +285,42 @@ int miseg_loss_grad(const float* gt, const float* pr, const double* sums, void* 
 int miseg_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t count,
                     float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* ------------------------------------------------------- the steps either side of the network ---
+ * Input contract and post-processing of utils/data.py and utils/predict.py on the device.  Images
+ * are NHWC with interleaved channels; `dtype` 0 = uint8, 1 = float32.
+ */
+
+/* Per-image minimum and maximum over all pixels and channels (normalize_image, utils/data.py:75-76).
+ * minmax: float[2*N] = (min_0, max_0, min_1, ...). */
+int miseg_image_minmax(const void* img, int32_t dtype, int32_t N, int64_t elems_per_image,
+                       float* minmax, void* stream);
+/* out = (img - min_n) / (max_n - min_n) as float32 (utils/data.py:78). */
+int miseg_image_normalize(const void* img, int32_t dtype, int32_t N, int64_t elems_per_image,
+                          const float* minmax, float* out, void* stream);
+/* tf.image.resize(image, (Ho, Wo), method="bilinear") (utils/data.py:138): half-pixel centres, no
+ * antialiasing; uint8 or float32 in, float32 out. */
+int miseg_resize_bilinear(const void* in, int32_t dtype, float* out, int32_t N, int32_t H, int32_t W,
+                          int32_t C, int32_t Ho, int32_t Wo, void* stream);
+/* Nearest-neighbour resize of uint8 images.  mode 0: tf.image.resize(method="nearest")
+ * (utils/data.py:136,164; source = floor((dst + 0.5) * scale)); mode 1: cv2.resize(...,
+ * INTER_NEAREST) (utils/predict.py:166; source = floor(dst * scale)). */
+int miseg_resize_nearest_u8(const uint8_t* in, uint8_t* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                            int32_t Ho, int32_t Wo, int32_t mode, void* stream);
+/* tf.one_hot(mask, depth=C, axis=2) as float32 (utils/data.py:51-54): ids uint8 [pixels] ->
+ * float32 [pixels][C]; an id >= C gives an all-zero pixel. */
+int miseg_one_hot(const uint8_t* ids, float* out, int64_t pixels, int32_t C, void* stream);
+/*
+ * augment_dataset (utils/data.py:240-295) with the random draws made by the caller: per image
+ * params[8] = {flip_left_right, flip_up_down, brightness delta, contrast factor, hue delta,
+ * saturation factor, contrast on, hue/saturation on}.  img: float32 RGB [N,H,W,3]; mask (optional):
+ * float32 [N,H,W,MC], flipped with the image.  Order: flips, brightness (x + delta), contrast
+ * ((x - mean_c) * f + mean_c, mean per image and channel), hue, saturation (through HSV).
+ * workspace: double[3*N].  Outputs must not alias inputs.
+ */
+int miseg_augment(const float* img, const float* mask, float* img_out, float* mask_out, int32_t N,
+                  int32_t H, int32_t W, int32_t MC, const float* params, double* workspace,
+                  void* stream);
+
 /*
  * A plan is a recorded list of the calls above with fixed arguments, replayed
  * with one call per forward pass (the analogue of the compiled tf.function

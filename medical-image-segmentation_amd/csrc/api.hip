@@ -43,6 +43,14 @@ int launch_bn_relu_bwd_apply(const void*, const void*, void*, long long, int, in
                              const float*, const float*, const float*, const float*, float, int,
                              const double*, const void*, int, hipStream_t);
 int launch_channel_sums(const void*, long long, int, int, double*, hipStream_t);
+int launch_image_minmax(const void*, int, int, long long, float*, hipStream_t);
+int launch_image_normalize(const void*, int, int, long long, const float*, float*, hipStream_t);
+int launch_resize_bilinear(const void*, int, float*, int, int, int, int, int, int, hipStream_t);
+int launch_resize_nearest_u8(const unsigned char*, unsigned char*, int, int, int, int, int, int, int,
+                             hipStream_t);
+int launch_one_hot(const unsigned char*, float*, long long, int, hipStream_t);
+int launch_augment(const float*, const float*, float*, float*, int, int, int, int, const float*, double*,
+                   hipStream_t);
 int launch_maxpool3x3s2_bwd(const void*, const void*, void*, int, int, int, int, int, int, int,
                             hipStream_t);
 int launch_avgpool2x2_bwd(const void*, void*, int, int, int, int, int, int, hipStream_t);
@@ -194,6 +202,31 @@ int miseg_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, int64_t pix
                             int32_t addend_pix_stride, void* stream) {
   return launch_bn_relu_bwd_apply(x, dy, dx, pixels, C, xps, dps, ops, scale, shift, mean, var, eps,
                                   relu, sums, addend, addend_pix_stride, (hipStream_t)stream);
+}
+int miseg_image_minmax(const void* img, int32_t dtype, int32_t N, int64_t elems, float* minmax,
+                       void* stream) {
+  return launch_image_minmax(img, dtype, N, elems, minmax, (hipStream_t)stream);
+}
+int miseg_image_normalize(const void* img, int32_t dtype, int32_t N, int64_t elems, const float* minmax,
+                          float* out, void* stream) {
+  return launch_image_normalize(img, dtype, N, elems, minmax, out, (hipStream_t)stream);
+}
+int miseg_resize_bilinear(const void* in, int32_t dtype, float* out, int32_t N, int32_t H, int32_t W,
+                          int32_t C, int32_t Ho, int32_t Wo, void* stream) {
+  return launch_resize_bilinear(in, dtype, out, N, H, W, C, Ho, Wo, (hipStream_t)stream);
+}
+int miseg_resize_nearest_u8(const uint8_t* in, uint8_t* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                            int32_t Ho, int32_t Wo, int32_t mode, void* stream) {
+  return launch_resize_nearest_u8(in, out, N, H, W, C, Ho, Wo, mode, (hipStream_t)stream);
+}
+int miseg_one_hot(const uint8_t* ids, float* out, int64_t pixels, int32_t C, void* stream) {
+  return launch_one_hot(ids, out, pixels, C, (hipStream_t)stream);
+}
+int miseg_augment(const float* img, const float* mask, float* img_out, float* mask_out, int32_t N,
+                  int32_t H, int32_t W, int32_t MC, const float* params, double* workspace,
+                  void* stream) {
+  return launch_augment(img, mask, img_out, mask_out, N, H, W, MC, params, workspace,
+                        (hipStream_t)stream);
 }
 int miseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
                            int32_t C, int32_t xps, int32_t dps, int32_t ops, void* stream) {

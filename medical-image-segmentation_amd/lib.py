@@ -88,6 +88,12 @@ SIGNATURES = {
                                   _I32, _VP]),
     "miseg_adam_step": (C.c_int, [_FP, _FP, _FP, _FP, _VP, _I64, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_float, _VP]),
+    "miseg_image_minmax": (C.c_int, [_VP, _I32, _I32, _I64, _FP, _VP]),
+    "miseg_image_normalize": (C.c_int, [_VP, _I32, _I32, _I64, _FP, _FP, _VP]),
+    "miseg_resize_bilinear": (C.c_int, [_VP, _I32, _FP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_resize_nearest_u8": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_one_hot": (C.c_int, [_VP, _FP, _I64, _I32, _VP]),
+    "miseg_augment": (C.c_int, [_FP, _FP, _FP, _FP, _I32, _I32, _I32, _I32, _FP, _VP, _VP]),
     "miseg_plan_create": (_VP, []),
     "miseg_plan_destroy": (None, [_VP]),
     "miseg_plan_num_ops": (C.c_int, [_VP]),
