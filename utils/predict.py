@@ -1,0 +1,96 @@
+"""Drop-in for the prediction loop of the reference's `utils/predict.py`
+(/root/reference utils/predict.py:17-72,75-166,277-286): load, resize, normalise, forward (whole
+image or the reference's border-anchored patches), collapse to class masks, resize back to the
+original size, write PNGs.  Decode and PNG encode run on the host (Pillow); everything between
+them runs on the GPU.  The OpenCV contour analysis that the reference can chain after the mask
+(`analyze_contours`, `reclassify`, `remove_artifacts`, `use_bias*`) is outside this package.
+"""
+import shutil
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from utils.data import list_files, load_image, reset_class_values
+from utils.model import get_model_input_shape, load_model
+from utils.utils import color_classes
+from miseg_amd import imageops as _ops, shard as _shard
+from miseg_amd.model import Model as _Model
+
+
+def patch_predict(model, image, patch_shape):
+    """Forward `image` (H,W,3 float32, host or device) in non-overlapping patches of the model's
+    input size; the last patch of each axis is shifted back to end at the border.  Returns the
+    (H,W,classes) float32 probabilities as a device tensor."""
+    input_shape = get_model_input_shape(model)
+    if tuple(input_shape) != tuple(patch_shape):
+        raise ValueError("The model's input shape does not match the patch shape: model '%s' != patch '%s'."
+                         % (input_shape, patch_shape))
+    if not isinstance(image, torch.Tensor):
+        image = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32))
+    image = image.cuda()
+    h, w = image.shape[:2]
+    out = None
+    for y0, y1 in _shard.tile_ranges(h, patch_shape[0]):
+        for x0, x1 in _shard.tile_ranges(w, patch_shape[1]):
+            pr = model(image[y0:y1, x0:x1].unsqueeze(0).contiguous(), training=False).tensor[0]
+            if out is None:
+                out = torch.zeros((h, w, pr.shape[-1]), dtype=torch.float32, device=pr.device)
+            out[y0:y1, x0:x1] = pr
+    return out
+
+
+def predict(model, images, normalize=True, input_shape=None, copy_images=False, grayscale=False,
+            analyze_contours=False, output_predictions="predictions", output_contour_analysis=None, bboxes=None,
+            classify_agnor=False, decision_tree_model_path="agnor_classifier.joblib", record_id=None,
+            record_class=None, measures_only=False, current_time=time.strftime("%Y%m%d%H%M%S"),
+            use_bias_layer=False, use_bias=False, reclassify=False, remove_artifacts=False):
+    """Segment one image file or every image of a directory and write `<stem>_prediction.png`
+    (class colours, or class indices with `grayscale`) under `output_predictions`."""
+    if analyze_contours or use_bias or use_bias_layer or reclassify or remove_artifacts or classify_agnor:
+        raise NotImplementedError("contour analysis and Papanicolaou post-processing are OpenCV tooling on the "
+                                  "CPU and are not part of this package; run them on the written masks")
+    if not isinstance(images, str):
+        raise ValueError("`images` must be a `str`. Given `%s`." % type(images))
+    if Path(images).is_dir():
+        files = list_files(images, as_numpy=True)
+    elif Path(images).is_file():
+        files = [images]
+    else:
+        raise FileNotFoundError("The directory or file was not found at `%s`." % images)
+    if isinstance(model, str):
+        model = load_model(model_path=model, input_shape=input_shape)
+    elif not isinstance(model, _Model):
+        raise ValueError("`model` must be a `str` or a model object. Given `%s`." % type(model))
+    if not input_shape:
+        input_shape = get_model_input_shape(model)
+    out_dir = Path(output_predictions)
+    out_dir.mkdir(exist_ok=True, parents=True)
+    from PIL import Image
+    for file in sorted(set(files)):
+        image, original_shape = load_image(image_path=file, normalize=normalize, shape=input_shape[:2],
+                                           return_original_shape=True)
+        image = image.float()
+        if tuple(image.shape) != tuple(input_shape):
+            probs = patch_predict(model, image, input_shape)
+            mask = _ops_collapse(probs)
+        else:
+            mask = torch.from_numpy(model.predict_masks(image.unsqueeze(0), pixel_intensity=127)[0]).cuda()
+        mask = _ops.masks_to_original_size(mask.unsqueeze(0), original_shape)[0].cpu().numpy()
+        if measures_only:
+            continue
+        picture = reset_class_values(mask) if grayscale else color_classes(mask.copy())
+        Image.fromarray(picture).save(str(out_dir.joinpath("%s_prediction.png" % Path(file).stem)))
+        if copy_images:
+            shutil.copyfile(str(file), str(out_dir.joinpath(Path(file).name)))
+
+
+def _ops_collapse(probs):
+    """Strict-argmax collapse of (H,W,C) device probabilities to a 0/127 uint8 mask."""
+    from miseg_amd import lib as L
+    lib = L.load()
+    out = torch.empty(probs.shape, dtype=torch.uint8, device=probs.device)
+    L.check(lib.miseg_collapse_u8(probs.contiguous().data_ptr(), out.data_ptr(), probs.shape[0] * probs.shape[1],
+                                  probs.shape[2], 127, torch.cuda.current_stream().cuda_stream))
+    return out
