@@ -64,6 +64,17 @@ def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
                       "(TensorFlow reference not installable offline)" % (n_done, h, w)}
 
 
+def pmc_traffic(kernel, batch, h, w, encoder, decoder):
+    """HBM bytes per launch of `kernel` from the committed counter passes (collected with the same
+    command at batch 4, 1920x2560, ResNet-34 U-Net); None for any other configuration."""
+    path = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    if not os.path.isfile(path) or (batch, h, w, encoder, decoder) != (4, 1920, 2560, "resnet34", "U-Net"):
+        return None
+    with open(path) as f:
+        k = json.load(f)["kernels"].get(kernel)
+    return k["hbm_bytes_per_launch"] if k else None
+
+
 def training_leg(args, dev, rank, world, dist, h, w):
     """Second headline configuration: ResNet-18 U-Net training steps (forward on batch statistics,
     cce+Dice loss, backward, bucketed gradient all-reduce over RCCL overlapped with the backward
@@ -204,10 +215,11 @@ def main():
         # group launches by device kernel (template instantiation), as rocprofv3 --stats does
         groups = {}
         for i in range(nops):
-            g = groups.setdefault(kernels[i], {"launches": 0, "ms": 0.0, "flops": 0.0})
+            g = groups.setdefault(kernels[i], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             g["launches"] += 1
             g["ms"] += op_ms[i]
             g["flops"] += 2.0 * macs[i]
+            g["bytes"] += eng.op_bytes[i]
         dom_name = max(groups, key=lambda k: groups[k]["ms"])
         dom = groups[dom_name]
         dom_tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -250,7 +262,10 @@ def main():
                 "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(dom_name, args.batch, h, w, args.encoder, args.decoder),
+                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes), "
+                                "from the committed PMC passes profiles/r01_d_pmc_*.csv",
+                "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                 "all_conv_launches": {
                     "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
                     "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,

@@ -81,6 +81,7 @@ class Engine:
         self._keep = []            # device tensors referenced by the plan
         self.taps = {}             # name -> View, for tests
         self.op_names = []
+        self.op_bytes = []        # algorithmic HBM bytes of each conv op: operands read once, results written once
         self.plan = C.c_void_p(self.lib.miseg_plan_create())
         self.x_in = torch.zeros((batch, self.h, self.wd, 3), dtype=torch.float32, device=self.device)
         self.probs = torch.zeros((batch, self.h, self.wd, self.classes), dtype=torch.float32,
@@ -157,9 +158,10 @@ class Engine:
         return self.dev_bf16(out.reshape(64, 7, 1, 32))
 
     # ------------------------------------------------------------------- ops
-    def _add(self, rc, name):
+    def _add(self, rc, name, nbytes=0):
         L.check(rc)
         self.op_names.append(name)
+        self.op_bytes.append(nbytes)
 
     def conv(self, name, x, wptr, cout, k, stride=1, pad=0, out=None, out_dtype=L.DT_BF16,
              scale=None, shift=None, act=L.ACT_NONE, residual=None, out2=None, scale2=None,
@@ -211,7 +213,17 @@ class Engine:
         d.collapse_out = collapse.data_ptr() if collapse is not None else None
         d.collapse_value = self.collapse_value
         d.tile_hint = tile_hint
-        self._add(self.lib.miseg_plan_add_conv(self.plan, C.byref(d)), name)
+        pix_out = x.n * oh * ow
+        nbytes = x.n * x.h * x.w * x.c * 2 + cout * d.KH * d.KW * cin * 2 * (4 if transposed else 1)
+        if out is not None:
+            nbytes += pix_out * cout * (4 if out_dtype == L.DT_F32 else 2)
+        if out2 is not None:
+            nbytes += pix_out * cout * 2
+        if residual is not None:
+            nbytes += pix_out * cout * residual.esize
+        if collapse is not None:
+            nbytes += pix_out * cout
+        self._add(self.lib.miseg_plan_add_conv(self.plan, C.byref(d)), name, nbytes)
 
     def conv_bn_relu(self, base, x, k, out=None):
         """segmentation_models Conv2dBn: <base>_conv -> <base>_bn -> relu."""
