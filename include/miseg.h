@@ -44,6 +44,7 @@ extern "C" {
 
 #define MISEG_TILE_NO_DMA 16
 #define MISEG_TILE_NO_HALO 32
+#define MISEG_TILE_SHARED_W 64  /* halo kernels: block-shared weight tiles instead of wave-private rings */
 
 const char* miseg_last_error(void);
 int miseg_version(void);

@@ -14,344 +14,9 @@
 // [BM pixels] x [BN couts] tile, double-buffered in LDS with one barrier per K-step.
 // Two staging paths: LDS-DMA (global_load_lds, BK = 64) for plain bf16 operands, and a
 // register-staged path (BK = 32) that can apply BatchNorm+ReLU to the operand on the way.
-#include <utility>
-
-#include "common.h"
+#include "conv_common.h"
 
 namespace miseg {
-
-// Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  Keeps
-// accumulator arrays indexed by constants only (a runtime index would move them to scratch).
-template <class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
-struct ConvParams {
-  const bf16_t* in;
-  const bf16_t* weight;
-  void* out;
-  bf16_t* out2;
-  const void* residual;
-  const float* scale;
-  const float* shift;
-  const float* scale2;
-  const float* shift2;
-  const float* in_scale;
-  const float* in_shift;
-  uint8_t* collapse_out;
-  int N, H, W, Cin;
-  int Ho, Wo, Cout;
-  int KH, KW, stride_y, stride_x, pad_y, pad_x;
-  int in_pix_stride, in_row_stride;
-  long long in_img_stride;
-  int out_pix_stride, out_row_stride;
-  long long out_img_stride;
-  int out2_pix_stride, out2_row_stride;
-  long long out2_img_stride;
-  int res_pix_stride, res_row_stride;
-  long long res_img_stride;
-  int out_dtype, res_dtype, act, transposed;
-  float inv_temperature;
-  int collapse_value;
-  int M;        // N*Ho*Wo
-  int mtiles;   // ceil(M / BM)
-  int ntiles;   // ceil(Cout / BN)
-  int vec_ok;   // strides/pointers allow 16-byte epilogue accesses
-  int tiles_y, tiles_x;  // halo kernel: output patches per image
-};
-
-// 16 zero bytes x 8: the source of LDS-DMA loads for taps that fall outside the image.
-__device__ __attribute__((aligned(128))) unsigned char g_zero_line[128];
-
-// LDS tile addressing.  Rows of 64 B (BK=32) hold 4 sixteen-byte chunks, rows of 128 B
-// (BK=64) hold 8; the chunk index is XOR-swizzled with row bits so that the 16 rows a
-// ds_read_b128 lane group touches land on 16 distinct 16-B slots of the 256-B bank row.
-__device__ __forceinline__ int swz64(int row, int chunk) {
-  return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
-}
-__device__ __forceinline__ int swz128(int row, int chunk) {
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-struct TileCoord {
-  int m0, cout0, ph_a, ph_b, pad_y, pad_x;
-  const bf16_t* wbase;
-};
-
-template <int BM, int BN>
-__device__ __forceinline__ TileCoord tile_coord(const ConvParams& p) {
-  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each of the 8
-  // groups a contiguous run of tiles, with the N-tiles of one M-tile adjacent.
-  TileCoord t;
-  // For transpose-conv the four phases of one tile are consecutive work items, so they run
-  // on the same XCD at about the same time and their interleaved output pixels merge in L2.
-  const int nph = p.transposed ? 4 : 1;
-  const int ntot = p.mtiles * p.ntiles * nph;
-  const int bid = blockIdx.x;
-  const int q = ntot >> 3, r = ntot & 7;
-  const int x = bid & 7, loc = bid >> 3;
-  const int item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-  const int phase = p.transposed ? (item & 3) : 0;
-  const int tile = p.transposed ? (item >> 2) : item;
-  const int mtile = tile / p.ntiles;
-  const int ntile = tile - mtile * p.ntiles;
-  t.m0 = mtile * BM;
-  t.cout0 = ntile * BN;
-  t.pad_y = p.pad_y;
-  t.pad_x = p.pad_x;
-  t.ph_a = t.ph_b = 0;
-  t.wbase = p.weight;
-  if (p.transposed) {
-    t.ph_a = phase >> 1;
-    t.ph_b = phase & 1;
-    t.pad_y = 1 - t.ph_a;
-    t.pad_x = 1 - t.ph_b;
-    t.wbase += (long long)phase * p.Cout * 4 * p.Cin;
-  }
-  return t;
-}
-
-// ---------------------------------------------------------------------------------
-// Epilogue.  The accumulators hold D[cout][pixel]; each wave transposes one 32-pixel
-// tile at a time through its own LDS region ([32 pixels][NT*32 couts] fp32, rows padded
-// by 16 B) so that every lane then owns 8 consecutive output channels of one pixel:
-// 16-byte bf16 stores (32-byte fp32), residual loads of the same shape, and the
-// channels of a pixel written by adjacent lanes.
-// ---------------------------------------------------------------------------------
-// Maps a pixel index inside a linear (row-major over N*Ho*Wo) block tile to coordinates.
-struct LinearDecode {
-  int m0, M, HoWo, Wo;
-  __device__ __forceinline__ bool operator()(int idx, int& n, int& oy, int& ox, int& rem) const {
-    const int m = m0 + idx;
-    if (m >= M) return false;
-    n = m / HoWo;
-    rem = m - n * HoWo;
-    oy = rem / Wo;
-    ox = rem - oy * Wo;
-    return true;
-  }
-};
-
-template <int WARPS_N, int MT, int NT, class Decode>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoord& tc,
-                                              const Decode& decode, f32x16 (&acc)[NT][MT],
-                                              unsigned char* lds, int wm, int wn, int lane) {
-  constexpr int TNW = NT * 32;       // couts per wave tile
-  constexpr int ROWF = TNW + 4;      // floats per LDS row
-  constexpr int LPP = TNW / 8;       // lanes per pixel when reading back
-  constexpr int PPP = 64 / LPP;      // pixels per pass
-  constexpr int PASSES = 32 / PPP;
-  const int wave = wm * WARPS_N + wn;
-  float* ep = reinterpret_cast<float*>(lds) + wave * (32 * ROWF);
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  const int HoWo = p.Ho * p.Wo;
-  const bool has_res = p.residual != nullptr;
-  const int px_l = lane / LPP;
-  const int co_l = (lane % LPP) * 8;
-  const int co = tc.cout0 + wn * TNW + co_l;
-  const bool full = co + 8 <= p.Cout && p.vec_ok;
-  const bool head = p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID;
-
-  static_for<MT>([&](auto bc) __attribute__((always_inline)) {
-    constexpr int b = decltype(bc)::value;
-    // The region is private to this wave and a wave's LDS operations execute in order, so
-    // no workgroup barrier is needed between the transposing writes and the reads below,
-    // nor before the next tile overwrites the region: only the compiler must keep the order.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *reinterpret_cast<float4*>(ep + lrow * ROWF + a * 32 + 8 * g + 4 * lhalf) =
-            make_float4(acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2],
-                        acc[a][b][4 * g + 3]);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      int px = ps * PPP + px_l;
-      int co_lx = co_l;
-      if (head) {
-        // softmax / sigmoid head (Cout <= 4): one pixel per lane, one pass
-        if (ps != 0 || lane >= 32) continue;
-        px = lane;
-        co_lx = 0;
-      }
-      const int cox = tc.cout0 + wn * TNW + co_lx;
-      const bool fullx = !head && full;
-      int n, oy, ox, rem;
-      if (cox >= p.Cout || !decode(wm * (MT * 32) + b * 32 + px, n, oy, ox, rem)) continue;
-      if (p.transposed) {
-        oy = 2 * oy + tc.ph_a;
-        ox = 2 * ox + tc.ph_b;
-      }
-      float v[8];
-      {
-        const float4 v0 = *reinterpret_cast<const float4*>(ep + px * ROWF + co_lx);
-        const float4 v1 = *reinterpret_cast<const float4*>(ep + px * ROWF + co_lx + 4);
-        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
-        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-      }
-      const long long o_off = n * p.out_img_stride + (long long)oy * p.out_row_stride +
-                              (long long)ox * p.out_pix_stride + cox;
-      const long long o2_off = n * p.out2_img_stride + (long long)oy * p.out2_row_stride +
-                               (long long)ox * p.out2_pix_stride + cox;
-      const long long r_off = n * p.res_img_stride + (long long)oy * p.res_row_stride +
-                              (long long)ox * p.res_pix_stride + cox;
-      if (fullx) {
-        if (p.scale) {
-          const float4 s0 = *reinterpret_cast<const float4*>(p.scale + cox);
-          const float4 s1 = *reinterpret_cast<const float4*>(p.scale + cox + 4);
-          v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w;
-          v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
-        }
-        if (p.shift) {
-          const float4 s0 = *reinterpret_cast<const float4*>(p.shift + cox);
-          const float4 s1 = *reinterpret_cast<const float4*>(p.shift + cox + 4);
-          v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w;
-          v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
-        }
-        if (has_res) {
-          if (p.res_dtype == MISEG_DT_F32) {
-            const float* rp = reinterpret_cast<const float*>(p.residual) + r_off;
-            const float4 r0 = *reinterpret_cast<const float4*>(rp);
-            const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
-            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-            v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-          } else {
-            const uint4 r = *reinterpret_cast<const uint4*>(
-                reinterpret_cast<const bf16_t*>(p.residual) + r_off);
-            v[0] += bf16lo_to_f32(r.x); v[1] += bf16hi_to_f32(r.x);
-            v[2] += bf16lo_to_f32(r.y); v[3] += bf16hi_to_f32(r.y);
-            v[4] += bf16lo_to_f32(r.z); v[5] += bf16hi_to_f32(r.z);
-            v[6] += bf16lo_to_f32(r.w); v[7] += bf16hi_to_f32(r.w);
-          }
-        }
-        if (p.out) {
-          float w[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) w[j] = p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
-          if (p.out_dtype == MISEG_DT_F32) {
-            float* o = reinterpret_cast<float*>(p.out) + o_off;
-            *reinterpret_cast<float4*>(o) = make_float4(w[0], w[1], w[2], w[3]);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(w[4], w[5], w[6], w[7]);
-          } else {
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o_off) =
-                make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]),
-                           pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
-          }
-        }
-        if (p.out2) {
-          const float4 s0 = *reinterpret_cast<const float4*>(p.scale2 + cox);
-          const float4 s1 = *reinterpret_cast<const float4*>(p.scale2 + cox + 4);
-          const float4 t0 = *reinterpret_cast<const float4*>(p.shift2 + cox);
-          const float4 t1 = *reinterpret_cast<const float4*>(p.shift2 + cox + 4);
-          *reinterpret_cast<uint4*>(p.out2 + o2_off) = make_uint4(
-              pack_bf16x2(fmaxf(v[0] * s0.x + t0.x, 0.f), fmaxf(v[1] * s0.y + t0.y, 0.f)),
-              pack_bf16x2(fmaxf(v[2] * s0.z + t0.z, 0.f), fmaxf(v[3] * s0.w + t0.w, 0.f)),
-              pack_bf16x2(fmaxf(v[4] * s1.x + t1.x, 0.f), fmaxf(v[5] * s1.y + t1.y, 0.f)),
-              pack_bf16x2(fmaxf(v[6] * s1.z + t1.z, 0.f), fmaxf(v[7] * s1.w + t1.w, 0.f)));
-        }
-        continue;
-      }
-      // ---- partial channel group (Cout tail, unaligned strides, or the softmax head) ----
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (cox + j < p.Cout) {
-          if (p.scale) v[j] *= p.scale[cox + j];
-          if (p.shift) v[j] += p.shift[cox + j];
-          if (has_res)
-            v[j] += p.res_dtype == MISEG_DT_F32
-                        ? reinterpret_cast<const float*>(p.residual)[r_off + j]
-                        : bf16_to_f32(reinterpret_cast<const bf16_t*>(p.residual)[r_off + j]);
-        }
-      }
-      if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID) {
-        // Cout <= 4: the whole channel vector of this pixel sits in this lane (cox == 0).
-        const int C = p.Cout;
-        float pr[4];
-        if (p.act == MISEG_ACT_SIGMOID) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) pr[j] = 1.f / (1.f + __expf(-v[j]));
-        } else {
-          float mx = -3.0e38f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < C) mx = fmaxf(mx, v[j] * p.inv_temperature);
-          float sum = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            pr[j] = j < C ? __expf(v[j] * p.inv_temperature - mx) : 0.f;
-            sum += pr[j];
-          }
-          const float inv = 1.f / sum;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) pr[j] *= inv;
-        }
-        float* o = reinterpret_cast<float*>(p.out) + o_off;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < C) o[j] = pr[j];
-        if (p.collapse_out) {
-          // in-place semantics of the reference loop: channel i is compared with the
-          // already collapsed values (0 or collapse_value) of channels j < i.
-          float cv[4];
-          const float val = (float)p.collapse_value;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            bool win = i < C;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (j == i || j >= C) continue;
-              const float other = j < i ? cv[j] : pr[j];
-              win = win && (pr[i] > other);
-            }
-            cv[i] = win ? val : 0.f;
-          }
-          uint8_t* c8 = p.collapse_out + ((long long)n * HoWo + rem) * C;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < C) c8[j] = (uint8_t)cv[j];
-        }
-        continue;
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (cox + j >= p.Cout) continue;
-        if (p.out) {
-          const float w = p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
-          if (p.out_dtype == MISEG_DT_F32)
-            reinterpret_cast<float*>(p.out)[o_off + j] = w;
-          else
-            reinterpret_cast<bf16_t*>(p.out)[o_off + j] = f32_to_bf16(w);
-        }
-        if (p.out2)
-          p.out2[o2_off + j] = f32_to_bf16(fmaxf(v[j] * p.scale2[cox + j] + p.shift2[cox + j], 0.f));
-      }
-    }
-  });
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT][MT]) {
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int b = 0; b < MT; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-}
-
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // ---------------------------------------------------------------------------------
 // Kernel A: register-staged, BK = 32.  Serves operands that need the BatchNorm+ReLU
@@ -662,18 +327,6 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
 // instead of a [BM][64] activation tile.  Weight tiles are double buffered per tap, the
 // next chunk's halo is fetched one wave-instruction per tap step.
 // ---------------------------------------------------------------------------------
-template <int TH, int TW>
-struct PatchDecode {
-  int n, y0, x0, Ho, Wo;
-  __device__ __forceinline__ bool operator()(int idx, int& n_, int& oy, int& ox, int& rem) const {
-    oy = y0 + idx / TW;
-    ox = x0 + idx % TW;
-    if (oy >= Ho || ox >= Wo) return false;
-    n_ = n;
-    rem = oy * Wo + ox;
-    return true;
-  }
-};
 
 template <int TH, int TW, int WARPS_M, int WARPS_N, int MT, int NT, int HB, bool CONVT>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(const ConvParams p) {
@@ -1079,7 +732,9 @@ int validate_conv(const miseg_conv_desc* d) {
   return MISEG_OK;
 }
 
-enum KernelKind { K_REG = 0, K_REG_PRO = 1, K_DMA = 2, K_HALO = 3, K_C32 = 4 };
+enum KernelKind { K_REG = 0, K_REG_PRO = 1, K_DMA = 2, K_HALO = 3, K_C32 = 4, K_HALO_PW = 5 };
+
+hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s);
 struct KernelChoice {
   KernelKind kind;
   int cfg;  // 1..7 index into kCfgs; 8..10 halo variants
@@ -1097,8 +752,13 @@ static KernelChoice choose_kernel(const miseg_conv_desc* d) {
                       d->Wo == d->W && d->Cin == 32 && d->Cout <= 32 &&
                       !(d->tile_hint & MISEG_TILE_NO_HALO);
   if (c32_ok && (hint == 0 || hint == 14)) return {K_C32, 14};
+  // wave-private weight rings: per-lane source offsets are 32-bit byte offsets from the image base
+  const bool pw_ok = hint == 0 && d->Cout > 64 && !(d->tile_hint & MISEG_TILE_SHARED_W) &&
+                     (long long)d->H * d->in_row_stride * 2 < (1ll << 31) &&
+                     (long long)d->Cout * 9 * d->Cin * 2 < (1ll << 31);
   const bool convt_ok = !pro && d->transposed && (d->Cin & 63) == 0 &&
                         !(d->tile_hint & MISEG_TILE_NO_HALO) && !(d->tile_hint & MISEG_TILE_NO_DMA);
+  if ((convt_ok || halo_ok) && pw_ok) return {K_HALO_PW, 0};
   if (convt_ok && (hint == 0 || hint == 11 || hint == 12 || hint == 15)) {
     if (hint) return {K_HALO, hint};
     return {K_HALO, d->Cout > 64 ? 11 : (d->Cout > 32 ? 12 : 15)};
@@ -1132,6 +792,8 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
                                 "", "8, 32, 4, 1, 2, 1, 1"};
   if (kc.kind == K_C32)
     snprintf(buf, len, "conv3x3_c32_kernel<8, 32>");
+  else if (kc.kind == K_HALO_PW)
+    snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, %s>", d->transposed ? "true" : "false");
   else if (kc.kind == K_HALO)
     snprintf(buf, len, "conv3x3_halo_kernel<%s, %s>", halos[kc.cfg - 8], d->transposed ? "true" : "false");
   else if (kc.kind == K_DMA)
@@ -1185,6 +847,11 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     p.tiles_x = (d->Wo + 31) / 32;
     p.mtiles = d->N * p.tiles_y * p.tiles_x;
     p.ntiles = 1;
+  } else if (kc.kind == K_HALO_PW) {
+    p.tiles_y = (d->Ho + 7) / 8;
+    p.tiles_x = (d->Wo + 31) / 32;
+    p.mtiles = d->N * p.tiles_y * p.tiles_x;
+    p.ntiles = (d->Cout + 127) / 128;
   } else if (kc.kind == K_HALO) {
     const int tw = (cfg == 10 || cfg == 13) ? 16 : 32;
     const int bn = cfg == 15 ? 32 : ((cfg == 9 || cfg == 12) ? 64 : 128);
@@ -1213,6 +880,14 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   if (d->scale2) p.vec_ok &= ((uintptr_t)d->scale2 & 15) == 0 && ((uintptr_t)d->shift2 & 15) == 0;
   if (d->act == MISEG_ACT_SOFTMAX || d->act == MISEG_ACT_SIGMOID) p.vec_ok = 0;
   hipError_t e;
+  if (kc.kind == K_HALO_PW) {
+    e = launch_halo_pw(p, grid, stream);
+    if (e != hipSuccess) {
+      set_error("conv launch failed: %s", hipGetErrorString(e));
+      return MISEG_E_HIP;
+    }
+    return MISEG_OK;
+  }
   switch (cfg) {
     case 1: e = launch_cfg<2, 2, 2, 2>(p, grid, pro, dma, stream); break;
     case 2: e = launch_cfg<4, 1, 2, 2>(p, grid, pro, dma, stream); break;
