@@ -111,6 +111,18 @@ typedef struct miseg_conv_desc {
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);
 
 /*
+ * The tail of the U-Net the reference builds at utils/model.py:176-186, as one kernel:
+ * `decoder_stage4b` (Conv2D 3x3 32 -> 32 + BatchNorm + ReLU, given as `body`: in, weight,
+ * scale, shift, act; its out pointers are ignored) followed by `final_conv` + activation
+ * (Conv2D 3x3 32 -> classes <= 4 with bias, softmax / sigmoid, given as `head`: weight,
+ * scale, shift, act, temperature, fp32 out, optional collapse_out / collapse_value as in
+ * utils/utils.py:50-68).  The 32-channel tensor between them stays on chip.  Same results as
+ * the two miseg_conv2d_fwd calls up to the summation order inside the head's matrix
+ * instruction.
+ */
+int miseg_conv_c32_head_fwd(const miseg_conv_desc* body, const miseg_conv_desc* head, void* stream);
+
+/*
  * Input contract of the encoders: fp32 NHWC image with 3 channels ->
  * bf16 [N][H+6][W+8][4] with the image at rows 3.., columns 3.., channel 3 and
  * the border zero; value = x*scale[c] + shift[c] (ResNet `bn_data`, a
@@ -332,6 +344,7 @@ miseg_plan* miseg_plan_create(void);
 void miseg_plan_destroy(miseg_plan* p);
 int miseg_plan_num_ops(const miseg_plan* p);
 int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d);
+int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, const miseg_conv_desc* head);
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
                               const float* shift, int32_t N, int32_t H, int32_t W);
 int miseg_plan_add_maxpool3x3s2(miseg_plan* p, const void* in, void* out, const float* scale,

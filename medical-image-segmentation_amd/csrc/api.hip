@@ -20,6 +20,8 @@ void set_error(const char* fmt, ...) {
 int launch_conv(const miseg_conv_desc* d, hipStream_t stream);
 int validate_conv(const miseg_conv_desc* d);
 void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len);
+int validate_conv_c32_head(const miseg_conv_desc* body, const miseg_conv_desc* head);
+int launch_conv_c32_head(const miseg_conv_desc* body, const miseg_conv_desc* head, hipStream_t stream);
 int launch_prep_input(const float*, void*, const float*, const float*, int, int, int, hipStream_t);
 int launch_maxpool3x3s2(const void*, void*, const float*, const float*, int, int, int, int, int,
                         int, hipStream_t);
@@ -62,11 +64,12 @@ int launch_loss_grad(const float*, const float*, const double*, void*, long long
 int launch_adam(float*, float*, float*, const float*, void*, long long, float, float, float, float,
                 float, hipStream_t);
 
-enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR };
+enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD };
 
 struct Op {
   OpKind kind;
   miseg_conv_desc conv;
+  miseg_conv_desc conv2;   // OP_CONV_HEAD: the head convolution
   const void* in;
   const void* in2;
   void* out;
@@ -79,6 +82,7 @@ struct Op {
 static int run_op(const Op& o, hipStream_t s) {
   switch (o.kind) {
     case OP_CONV: return launch_conv(&o.conv, s);
+    case OP_CONV_HEAD: return launch_conv_c32_head(&o.conv, &o.conv2, s);
     case OP_PREP: return launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
@@ -128,6 +132,10 @@ int miseg_device_check(void) {
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream) {
   return launch_conv(d, (hipStream_t)stream);
+}
+
+int miseg_conv_c32_head_fwd(const miseg_conv_desc* body, const miseg_conv_desc* head, void* stream) {
+  return launch_conv_c32_head(body, head, (hipStream_t)stream);
 }
 
 int miseg_prep_input(const float* in, void* out, const float* scale, const float* shift, int32_t N,
@@ -280,6 +288,18 @@ int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d) {
   return MISEG_OK;
 }
 
+int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, const miseg_conv_desc* head) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  int rc = validate_conv_c32_head(body, head);
+  if (rc != MISEG_OK) return rc;
+  Op o{};
+  o.kind = OP_CONV_HEAD;
+  o.conv = *body;
+  o.conv2 = *head;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
                               const float* shift, int32_t N, int32_t H, int32_t W) {
   MISEG_CHECK_ARG(p, "plan: null plan");
@@ -377,9 +397,10 @@ int miseg_plan_run(const miseg_plan* p, void* stream) {
 int64_t miseg_plan_op_macs(const miseg_plan* p, int index) {
   if (!p || index < 0 || index >= (int)p->ops.size()) return 0;
   const Op& o = p->ops[index];
-  if (o.kind != OP_CONV) return 0;
+  if (o.kind != OP_CONV && o.kind != OP_CONV_HEAD) return 0;
   const miseg_conv_desc& d = o.conv;
   const int64_t per = (int64_t)d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin;
+  if (o.kind == OP_CONV_HEAD) return per + (int64_t)d.N * d.Ho * d.Wo * o.conv2.Cout * 9 * o.conv2.Cin;
   return d.transposed ? 4 * per : per;
 }
 
@@ -392,6 +413,8 @@ int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t bufl
                                 "scale_shift_relu_kernel"};
   if (o.kind == OP_CONV)
     conv_kernel_name(&o.conv, buf, buflen);
+  else if (o.kind == OP_CONV_HEAD)
+    snprintf(buf, buflen, "conv3x3_c32_head_kernel");
   else
     snprintf(buf, buflen, "%s", names[o.kind]);
   return MISEG_OK;

@@ -74,21 +74,24 @@ struct TileCoord {
   const bf16_t* wbase;
 };
 
-template <int BM, int BN>
+// PHASES = false: a transpose-conv kernel that computes all four phases of a tile in one block
+// (one work item per tile; the caller sets phase and weight base per wave).
+template <int BM, int BN, bool PHASES = true>
 __device__ __forceinline__ TileCoord tile_coord(const ConvParams& p) {
   // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each of the 8
   // groups a contiguous run of tiles, with the N-tiles of one M-tile adjacent.
   TileCoord t;
   // For transpose-conv the four phases of one tile are consecutive work items, so they run
   // on the same XCD at about the same time and their interleaved output pixels merge in L2.
-  const int nph = p.transposed ? 4 : 1;
+  const bool phased = PHASES && p.transposed;
+  const int nph = phased ? 4 : 1;
   const int ntot = p.mtiles * p.ntiles * nph;
   const int bid = blockIdx.x;
   const int q = ntot >> 3, r = ntot & 7;
   const int x = bid & 7, loc = bid >> 3;
   const int item = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-  const int phase = p.transposed ? (item & 3) : 0;
-  const int tile = p.transposed ? (item >> 2) : item;
+  const int phase = phased ? (item & 3) : 0;
+  const int tile = phased ? (item >> 2) : item;
   const int mtile = tile / p.ntiles;
   const int ntile = tile - mtile * p.ntiles;
   t.m0 = mtile * BM;
@@ -97,7 +100,7 @@ __device__ __forceinline__ TileCoord tile_coord(const ConvParams& p) {
   t.pad_x = p.pad_x;
   t.ph_a = t.ph_b = 0;
   t.wbase = p.weight;
-  if (p.transposed) {
+  if (phased) {
     t.ph_a = phase >> 1;
     t.ph_b = phase & 1;
     t.pad_y = 1 - t.ph_a;
@@ -105,6 +108,57 @@ __device__ __forceinline__ TileCoord tile_coord(const ConvParams& p) {
     t.wbase += (long long)phase * p.Cout * 4 * p.Cin;
   }
   return t;
+}
+
+// Softmax (with temperature) or sigmoid over the <= 4 logits of one pixel, fp32 probabilities to
+// `o`, and the reference's collapse_probabilities mask to `c8` (utils/utils.py:50-68): channel i
+// is compared in place with the already collapsed values (0 or collapse_value) of channels j < i.
+__device__ __forceinline__ void head_eval(const ConvParams& p, const float* v, float (&pr)[4], float (&cv)[4]) {
+  const int C = p.Cout;
+  if (p.act == MISEG_ACT_SIGMOID) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pr[j] = 1.f / (1.f + __expf(-v[j]));
+  } else {
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < C) mx = fmaxf(mx, v[j] * p.inv_temperature);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pr[j] = j < C ? __expf(v[j] * p.inv_temperature - mx) : 0.f;
+      sum += pr[j];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pr[j] *= inv;
+  }
+  const float val = (float)p.collapse_value;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bool win = i < C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j == i || j >= C) continue;
+      const float other = j < i ? cv[j] : pr[j];
+      win = win && (pr[i] > other);
+    }
+    cv[i] = win ? val : 0.f;
+  }
+}
+
+__device__ __forceinline__ void head_store(const ConvParams& p, const float* v, float* o, uint8_t* c8) {
+  const int C = p.Cout;
+  float pr[4], cv[4];
+  head_eval(p, v, pr, cv);
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < C) o[j] = pr[j];
+  if (c8) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < C) c8[j] = (uint8_t)cv[j];
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -131,13 +185,14 @@ struct LinearDecode {
 template <int WARPS_N, int MT, int NT, class Decode>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoord& tc,
                                               const Decode& decode, f32x16 (&acc)[NT][MT],
-                                              unsigned char* lds, int wm, int wn, int lane) {
+                                              unsigned char* lds, int wm, int wn, int lane,
+                                              int ep_slot = -1) {
   constexpr int TNW = NT * 32;       // couts per wave tile
   constexpr int ROWF = TNW + 4;      // floats per LDS row
   constexpr int LPP = TNW / 8;       // lanes per pixel when reading back
   constexpr int PPP = 64 / LPP;      // pixels per pass
   constexpr int PASSES = 32 / PPP;
-  const int wave = wm * WARPS_N + wn;
+  const int wave = ep_slot >= 0 ? ep_slot : wm * WARPS_N + wn;   // which LDS region
   float* ep = reinterpret_cast<float*>(lds) + wave * (32 * ROWF);
   const int lrow = lane & 31, lhalf = lane >> 5;
   const int HoWo = p.Ho * p.Wo;
@@ -265,51 +320,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
       }
       if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID) {
         // Cout <= 4: the whole channel vector of this pixel sits in this lane (cox == 0).
-        const int C = p.Cout;
-        float pr[4];
-        if (p.act == MISEG_ACT_SIGMOID) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) pr[j] = 1.f / (1.f + __expf(-v[j]));
-        } else {
-          float mx = -3.0e38f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < C) mx = fmaxf(mx, v[j] * p.inv_temperature);
-          float sum = 0.f;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            pr[j] = j < C ? __expf(v[j] * p.inv_temperature - mx) : 0.f;
-            sum += pr[j];
-          }
-          const float inv = 1.f / sum;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) pr[j] *= inv;
-        }
-        float* o = reinterpret_cast<float*>(p.out) + o_off;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < C) o[j] = pr[j];
-        if (p.collapse_out) {
-          // in-place semantics of the reference loop: channel i is compared with the
-          // already collapsed values (0 or collapse_value) of channels j < i.
-          float cv[4];
-          const float val = (float)p.collapse_value;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            bool win = i < C;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (j == i || j >= C) continue;
-              const float other = j < i ? cv[j] : pr[j];
-              win = win && (pr[i] > other);
-            }
-            cv[i] = win ? val : 0.f;
-          }
-          uint8_t* c8 = p.collapse_out + ((long long)n * HoWo + rem) * C;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (j < C) c8[j] = (uint8_t)cv[j];
-        }
+        head_store(p, v, reinterpret_cast<float*>(p.out) + o_off,
+                   p.collapse_out ? p.collapse_out + ((long long)n * HoWo + rem) * p.Cout : nullptr);
         continue;
       }
 #pragma unroll
@@ -353,5 +365,29 @@ struct PatchDecode {
     return true;
   }
 };
+
+// LDS read the compiler does not track: the caller waits with lgkm_wait before using dst.
+template <int OFF>
+__device__ __forceinline__ void ds_read_b128_at(bf16x8& dst, unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read immediate offset is 16 bits");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+// Waits until at most CNT LDS operations are outstanding; `frag` is threaded through so that
+// its consumer cannot be scheduled above the wait.
+template <int CNT>
+__device__ __forceinline__ void lgkm_wait(bf16x8& frag) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(CNT));
+}
+
+
+// Waits until at most CNT LDS operations are outstanding, threading several fragments through.
+template <int CNT>
+__device__ __forceinline__ void lgkm_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
+}
+template <int CNT>
+__device__ __forceinline__ void lgkm_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(CNT));
+}
 
 }  // namespace miseg

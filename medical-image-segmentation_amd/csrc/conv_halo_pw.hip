@@ -39,19 +39,6 @@ constexpr int PW_WST = 32 * 128;                 // one ring slot: [32 couts][64
 constexpr int PW_LDS = PW_HALO_BYTES + 4 * 2 * PW_WST;
 static_assert(2 * PW_LDS <= 160 * 1024, "two blocks per CU");
 
-// LDS read the compiler does not track: the caller waits with lgkm_wait before using dst.
-template <int OFF>
-__device__ __forceinline__ void ds_read_b128_at(bf16x8& dst, unsigned addr) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds_read immediate offset is 16 bits");
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-}
-// Waits until at most CNT LDS operations are outstanding; `frag` is threaded through so that
-// its consumer cannot be scheduled above the wait.
-template <int CNT>
-__device__ __forceinline__ void lgkm_wait(bf16x8& frag) {
-  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(CNT));
-}
-
 }  // namespace
 
 template <int WARPS_M, int MT, bool CONVT>
@@ -62,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   constexpr int TAPS = CONVT ? 4 : 9;
   constexpr int TAPW = CONVT ? 2 : 3;
   constexpr int BM = TH * TW;
-  constexpr int BN = WARPS_N * 32;
+  constexpr int BN = CONVT ? 32 : WARPS_N * 32;   // transpose-conv: the four waves are the four phases
   constexpr int NHW = PW_NHI / 4;                 // halo wave-instructions per wave
   static_assert(PW_NHI % 4 == 0, "halo instructions split evenly over the waves");
   constexpr int WOFF = PW_HALO_BYTES;
@@ -75,7 +62,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WARPS_N;
   const int wn = wave % WARPS_N;
-  const TileCoord tc = tile_coord<BM, BN>(p);
+  TileCoord tc = tile_coord<BM, BN, false>(p);
+  const int cgrp = CONVT ? 0 : wn;               // 32-cout group of this wave inside the block
+  if (CONVT) {
+    tc.ph_a = wn >> 1;
+    tc.ph_b = wn & 1;
+    tc.wbase = p.weight + (long long)wn * p.Cout * 4 * p.Cin;
+  }
   const int mtile = tc.m0 / BM;
   const int per_img = p.tiles_y * p.tiles_x;
   const int n = mtile / per_img;
@@ -113,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = j * 8 + r8;
-      const int co = tc.cout0 + wn * 32 + row;
+      const int co = tc.cout0 + cgrp * 32 + row;
       const int ch = slot ^ ((row >> 1) & 7);
       w_off[j] = co < p.Cout ? (co * TAPS * p.Cin + ch * 8) * 2 : -1;
     }
@@ -238,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
 #undef MISEG_LGKM_WAIT
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
-  conv_epilogue<WARPS_N, MT, 1>(p, tc, dec, acc, lds, wm, wn, lane);
+  conv_epilogue<WARPS_N, MT, 1>(p, tc, dec, acc, lds, wm, cgrp, lane, wave);
 }
 
 hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s) {

@@ -753,9 +753,9 @@ static KernelChoice choose_kernel(const miseg_conv_desc* d) {
                       !(d->tile_hint & MISEG_TILE_NO_HALO);
   if (c32_ok && (hint == 0 || hint == 14)) return {K_C32, 14};
   // wave-private weight rings: per-lane source offsets are 32-bit byte offsets from the image base
-  const bool pw_ok = hint == 0 && d->Cout > 64 && !(d->tile_hint & MISEG_TILE_SHARED_W) &&
+  const bool pw_ok = hint == 0 && (d->Cout > 64 || d->transposed) && !(d->tile_hint & MISEG_TILE_SHARED_W) &&
                      (long long)d->H * d->in_row_stride * 2 < (1ll << 31) &&
-                     (long long)d->Cout * 9 * d->Cin * 2 < (1ll << 31);
+                     (long long)d->Cout * 16 * d->Cin * 2 < (1ll << 31);
   const bool convt_ok = !pro && d->transposed && (d->Cin & 63) == 0 &&
                         !(d->tile_hint & MISEG_TILE_NO_HALO) && !(d->tile_hint & MISEG_TILE_NO_DMA);
   if ((convt_ok || halo_ok) && pw_ok) return {K_HALO_PW, 0};
@@ -803,10 +803,7 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
              kc.kind == K_REG_PRO ? "true" : "false");
 }
 
-int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
-  int rc = validate_conv(d);
-  if (rc != MISEG_OK) return rc;
-  ConvParams p;
+static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.in = (const bf16_t*)d->in;
   p.weight = (const bf16_t*)d->weight;
   p.out = d->out;
@@ -837,6 +834,13 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   p.inv_temperature = d->act == MISEG_ACT_SOFTMAX ? 1.f / d->temperature : 1.f;
   p.collapse_value = d->collapse_value;
   p.M = d->N * d->Ho * d->Wo;
+}
+
+int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
+  int rc = validate_conv(d);
+  if (rc != MISEG_OK) return rc;
+  ConvParams p;
+  fill_params(d, p);
   const KernelChoice kc = choose_kernel(d);
   const int cfg = kc.cfg;
   const bool pro = kc.kind == K_REG_PRO;
@@ -851,7 +855,7 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     p.tiles_y = (d->Ho + 7) / 8;
     p.tiles_x = (d->Wo + 31) / 32;
     p.mtiles = d->N * p.tiles_y * p.tiles_x;
-    p.ntiles = (d->Cout + 127) / 128;
+    p.ntiles = d->transposed ? (d->Cout + 31) / 32 : (d->Cout + 127) / 128;
   } else if (kc.kind == K_HALO) {
     const int tw = (cfg == 10 || cfg == 13) ? 16 : 32;
     const int bn = cfg == 15 ? 32 : ((cfg == 9 || cfg == 12) ? 64 : 128);
@@ -864,7 +868,8 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     p.mtiles = (p.M + tc.bm - 1) / tc.bm;
     p.ntiles = (d->Cout + tc.bn - 1) / tc.bn;
   }
-  const dim3 grid(p.mtiles * p.ntiles * (d->transposed ? 4 : 1), 1, 1);
+  // the wave-private-ring kernel computes the four transpose-conv phases in one block
+  const dim3 grid(p.mtiles * p.ntiles * ((d->transposed && kc.kind != K_HALO_PW) ? 4 : 1), 1, 1);
   auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
     return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
   };
@@ -940,6 +945,62 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   }
   if (e != hipSuccess) {
     set_error("conv launch failed: %s", hipGetErrorString(e));
+    return MISEG_E_HIP;
+  }
+  return MISEG_OK;
+}
+
+hipError_t launch_c32_head(const ConvParams& body, const ConvParams& head, dim3 grid, hipStream_t s);
+
+// The last U-Net decoder convolution (3x3, 32 -> 32, scale/shift, ReLU) and the segmentation
+// head (3x3, 32 -> classes <= 4, softmax / sigmoid, optional collapse mask) in one kernel.
+int validate_conv_c32_head(const miseg_conv_desc* b, const miseg_conv_desc* h) {
+  MISEG_CHECK_ARG(b && h, "conv_c32_head: null descriptor");
+  MISEG_CHECK_ARG(b->in && b->weight && h->weight && h->out, "conv_c32_head: null pointer");
+  MISEG_CHECK_ARG(b->N > 0 && b->H > 0 && b->W > 0, "conv_c32_head: non-positive dimension");
+  auto shape3x3 = [](const miseg_conv_desc* d) {
+    return d->KH == 3 && d->KW == 3 && d->stride_y == 1 && d->stride_x == 1 && d->pad_y == 1 &&
+           d->pad_x == 1 && d->Ho == d->H && d->Wo == d->W && !d->transposed && d->Cin == 32;
+  };
+  if (!shape3x3(b) || !shape3x3(h) || b->Cout != 32 || h->Cout < 1 || h->Cout > 4) {
+    set_error("conv_c32_head: needs 3x3 stride-1 pad-1 convolutions 32 -> 32 -> (1..4) channels");
+    return MISEG_E_UNSUPPORTED_SHAPE;
+  }
+  MISEG_CHECK_ARG(h->N == b->N && h->H == b->H && h->W == b->W, "conv_c32_head: body and head extents differ");
+  MISEG_CHECK_ARG(!b->residual && !b->out2 && !b->in_scale && !h->residual && !h->out2 && !h->in_scale,
+                  "conv_c32_head: residual, second output and input prologue are not supported");
+  MISEG_CHECK_ARG(b->act == MISEG_ACT_NONE || b->act == MISEG_ACT_RELU, "conv_c32_head: body activation");
+  MISEG_CHECK_ARG((h->act == MISEG_ACT_SOFTMAX || h->act == MISEG_ACT_SIGMOID) &&
+                      h->out_dtype == MISEG_DT_F32 && h->temperature > 0.f,
+                  "conv_c32_head: head needs softmax/sigmoid, fp32 output, positive temperature");
+  MISEG_CHECK_ARG((b->in_pix_stride & 7) == 0 && (b->in_row_stride & 7) == 0 && (b->in_img_stride & 7) == 0 &&
+                      ((uintptr_t)b->in & 15) == 0 && ((uintptr_t)b->weight & 15) == 0 &&
+                      ((uintptr_t)h->weight & 15) == 0,
+                  "conv_c32_head: input/weights need 16-byte alignment and strides in multiples of 8");
+  if (b->scale) MISEG_CHECK_ARG(((uintptr_t)b->scale & 15) == 0, "conv_c32_head: scale misaligned");
+  if (b->shift) MISEG_CHECK_ARG(((uintptr_t)b->shift & 15) == 0, "conv_c32_head: shift misaligned");
+  return MISEG_OK;
+}
+
+int launch_conv_c32_head(const miseg_conv_desc* b, const miseg_conv_desc* h, hipStream_t stream) {
+  int rc = validate_conv_c32_head(b, h);
+  if (rc != MISEG_OK) return rc;
+  ConvParams pb, ph;
+  fill_params(b, pb);
+  fill_params(h, ph);
+  pb.tiles_y = (b->H + 7) / 8;
+  pb.tiles_x = (b->W + 31) / 32;
+  pb.mtiles = b->N * pb.tiles_y * pb.tiles_x;
+  pb.ntiles = 1;
+  pb.vec_ok = ph.vec_ok = 0;
+  ph.tiles_y = pb.tiles_y; ph.tiles_x = pb.tiles_x; ph.mtiles = pb.mtiles; ph.ntiles = 1;
+  // persistent blocks, two per CU
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const int blocks = pb.mtiles < 2 * cus ? pb.mtiles : 2 * cus;
+  hipError_t e = launch_c32_head(pb, ph, dim3(blocks), stream);
+  if (e != hipSuccess) {
+    set_error("conv_c32_head launch failed: %s", hipGetErrorString(e));
     return MISEG_E_HIP;
   }
   return MISEG_OK;

@@ -64,7 +64,7 @@ def _ceil32(c):
 
 class Engine:
     def __init__(self, graph, weights, batch=1, device="cuda:0", collapse_value=127,
-                 keep_logits=False):
+                 keep_logits=False, fuse_tail=True):
         """graph: netspec.Graph; weights: {layer: {weight_name: np.ndarray fp32}}."""
         if not torch.cuda.is_available():
             raise L.MisegError("no GPU visible: the HIP engine has no CPU fallback")
@@ -75,6 +75,8 @@ class Engine:
         self.g = graph
         self.w = weights
         self.n = batch
+        # U-Net: decoder_stage4b and final_conv as one kernel (the tensor between them stays on chip)
+        self.fuse_tail = fuse_tail
         self.h, self.wd, _ = graph.input_shape
         self.classes = graph.classes
         self.collapse_value = collapse_value
@@ -166,7 +168,7 @@ class Engine:
     def conv(self, name, x, wptr, cout, k, stride=1, pad=0, out=None, out_dtype=L.DT_BF16,
              scale=None, shift=None, act=L.ACT_NONE, residual=None, out2=None, scale2=None,
              shift2=None, in_scale=None, in_shift=None, transposed=False, collapse=None,
-             temperature=1.0, tile_hint=0):
+             temperature=1.0, tile_hint=0, build_only=False):
         d = L.ConvDesc()
         cin = _ceil32(x.c)
         if x.c0 + cin > x.ctot:
@@ -223,6 +225,8 @@ class Engine:
             nbytes += pix_out * cout * residual.esize
         if collapse is not None:
             nbytes += pix_out * cout
+        if build_only:
+            return d, nbytes
         self._add(self.lib.miseg_plan_add_conv(self.plan, C.byref(d)), name, nbytes)
 
     def conv_bn_relu(self, base, x, k, out=None):
@@ -367,13 +371,28 @@ class Engine:
         return out
 
     # -------------------------------------------------------------- decoders
-    def _head(self, name, x):
+    def _head(self, name, x, build_only=False):
         act = L.ACT_SIGMOID if self.g.activation == "sigmoid" else L.ACT_SOFTMAX
         temp = self.g.temperature if self.g.temperature is not None else 1.0
         out = View(self.probs, self.n, self.h, self.wd, self.classes)
-        self.conv(name, x, self.conv_weight(name), self.classes, 3, pad=1, out=out,
-                  out_dtype=L.DT_F32, shift=self.w[name]["bias"], act=act, collapse=self.mask,
-                  temperature=temp)
+        return self.conv(name, x, self.conv_weight(name), self.classes, 3, pad=1, out=out,
+                         out_dtype=L.DT_F32, shift=self.w[name]["bias"], act=act, collapse=self.mask,
+                         temperature=temp, build_only=build_only)
+
+    def _unet_tail(self, base, x, head):
+        """decoder_stage4b (Conv2dBn 3x3 32 -> 32) + final_conv + activation as one kernel: the
+        32-channel full-resolution tensor between the two is not written to HBM."""
+        cout = self.w[base + "_conv"]["kernel"].shape[3]
+        s, t = self.bn_fold(base + "_bn")
+        body, nb = self.conv(base, x, self.conv_weight(base + "_conv"), cout, 3, pad=1, scale=s, shift=t,
+                             act=L.ACT_RELU, build_only=True)
+        # descriptor of the head as it would run on the (virtual) 32-channel tensor
+        virt = View(torch.empty((0, 32), dtype=torch.bfloat16, device=self.device), self.n, x.h, x.w, cout)
+        hd, nh = self._head(head, virt, build_only=True)
+        hd.inp = None
+        nh -= self.n * x.h * x.w * cout * 2
+        self._add(self.lib.miseg_plan_add_conv_c32_head(self.plan, C.byref(body), C.byref(hd)),
+                  base + "+" + head, nb + nh)
 
     def _lower(self):
         g = self.g
@@ -403,8 +422,15 @@ class Engine:
                 cb = concat[i]
                 self.convT_bn_relu("decoder_stage%da_transpose" % i, "decoder_stage%da_bn" % i, x,
                                    out=cb.slice(0, f))
-                x = self.conv_bn_relu("decoder_stage%db" % i, cb.slice(0, f + (skips[i].c if i < 4 else 0)), 3)
-            self._head("final_conv", x)
+                xin = cb.slice(0, f + (skips[i].c if i < 4 else 0))
+                if i == 4 and self.fuse_tail and _ceil32(xin.c) == 32 and self.classes <= 4 and \
+                        self.w["decoder_stage4b_conv"]["kernel"].shape[3] == 32:
+                    self._unet_tail("decoder_stage4b", xin, "final_conv")
+                    x = None
+                else:
+                    x = self.conv_bn_relu("decoder_stage%db" % i, xin, 3)
+            if x is not None:
+                self._head("final_conv", x)
         elif dec == "Linknet":
             for i in range(5):
                 x = self.conv_bn_relu("decoder_stage%da" % i, x, 1)

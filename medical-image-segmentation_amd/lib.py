@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MISEG_LIB") or os.path.join(_HERE, "libmiseg.so")   # MISEG_LIB: experiments
 
 OK = 0
+E_INVALID_ARG, E_UNSUPPORTED_SHAPE, E_HIP, E_NO_DEVICE = -1, -2, -3, -4
 DT_BF16, DT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTMAX, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     "miseg_version": (C.c_int, []),
     "miseg_device_check": (C.c_int, []),
     "miseg_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _VP]),
+    "miseg_conv_c32_head_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _VP]),
     "miseg_prep_input": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
     "miseg_maxpool3x3s2_fwd": (C.c_int, [_VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_avgpool2x2_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
@@ -98,6 +100,7 @@ SIGNATURES = {
     "miseg_plan_destroy": (None, [_VP]),
     "miseg_plan_num_ops": (C.c_int, [_VP]),
     "miseg_plan_add_conv": (C.c_int, [_VP, C.POINTER(ConvDesc)]),
+    "miseg_plan_add_conv_c32_head": (C.c_int, [_VP, C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "miseg_plan_add_prep_input": (C.c_int, [_VP, _FP, _VP, _FP, _FP, _I32, _I32, _I32]),
     "miseg_plan_add_maxpool3x3s2": (C.c_int, [_VP, _VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32]),
     "miseg_plan_add_avgpool2x2": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
