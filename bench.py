@@ -67,7 +67,7 @@ def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
 def pmc_traffic(kernel, batch, h, w, encoder, decoder):
     """HBM bytes per launch of `kernel` from the committed counter passes (collected with the same
     command at batch 4, 1920x2560, ResNet-34 U-Net); None for any other configuration."""
-    path = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
     if not os.path.isfile(path) or (batch, h, w, encoder, decoder) != (4, 1920, 2560, "resnet34", "U-Net"):
         return None
     with open(path) as f:
@@ -128,7 +128,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=4, help="images per plan (one launch sequence)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent plans per GPU, each on its own HIP stream; a step runs every plan once "
+                         "(images per GPU per step = batch x streams)")
     ap.add_argument("--height", type=int, default=1920)
     ap.add_argument("--width", type=int, default=2560)
     ap.add_argument("--encoder", default="resnet34")
@@ -167,23 +170,33 @@ def main():
     h, w = args.height, args.width
     graph = netspec.build_graph(args.encoder, args.decoder, (h, w, 3), args.classes)
     weights = build_weights(graph)
-    eng = engine.Engine(graph, weights, batch=args.batch, device=str(dev))
-    x = torch.from_numpy(synthetic_images(args.batch, h, w, seed=1234 + rank)).to(dev)
-    eng.x_in.copy_(x)
+    # Images are independent: each plan owns its buffers and runs on its own stream, so the tail of
+    # one plan's kernel overlaps the head of another's.
+    engs = [engine.Engine(graph, weights, batch=args.batch, device=str(dev)) for _ in range(args.streams)]
+    streams = [torch.cuda.Stream(dev) for _ in range(args.streams)]
+    eng = engs[0]
+    for i, e in enumerate(engs):
+        x = torch.from_numpy(synthetic_images(args.batch, h, w, seed=1234 + rank * args.streams + i)).to(dev)
+        e.x_in.copy_(x)
     torch.cuda.synchronize()
+
+    def step():
+        for e, s in zip(engs, streams):
+            with torch.cuda.stream(s):
+                e.run()
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
     for _ in range(args.warmup):
-        eng.run()
+        step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.run()
+        step()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -233,9 +246,12 @@ def main():
                       (k, g["launches"], g["ms"], g["ms"] / g["launches"],
                        g["flops"] / (g["ms"] * 1e-3) / 1e12), file=sys.stderr)
             print("sum of per-op times %.3f ms (conv %.3f ms)" % (op_ms.sum(), conv_ms), file=sys.stderr)
-        images = args.batch * world * args.steps
+        per_step = args.batch * args.streams
+        images = per_step * world * args.steps
+        enc_names = {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "densenet169": "DenseNet-169"}
         result = {
-            "metric": "images/sec at 1920x2560x3 ResNet-34 U-Net inference",
+            "metric": "images/sec at %dx%dx3 %s %s inference" % (h, w, enc_names.get(args.encoder, args.encoder),
+                                                                  args.decoder),
             "value": images / elapsed,
             "unit": "images/s",
             "n_gpus": world,
@@ -248,9 +264,10 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": "%s %s inference %dx%dx3, %d classes, random-init weights, "
-                                   "batch %d per GPU per step" %
-                                   (args.encoder, args.decoder, h, w, args.classes, args.batch),
-                       "images_per_step_per_gpu": args.batch,
+                                   "%d images per GPU per step (%d concurrent plans of %d images)" %
+                                   (args.encoder, args.decoder, h, w, args.classes, per_step, args.streams,
+                                    args.batch),
+                       "images_per_step_per_gpu": per_step,
                        "parallelism": "independent images per GPU, no collective"},
             "roofline": {
                 "bound": "mfma",
@@ -259,12 +276,13 @@ def main():
                 "avg_launch_ms": dom["ms"] / dom["launches"],
                 "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
                 "achieved": dom_tflops,
+                "timing": "HIP events on the launch stream, one plan at a time (averaged over 5 passes)",
                 "peak": MFMA_BF16_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": pmc_traffic(dom_name, args.batch, h, w, args.encoder, args.decoder),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes), "
-                                "from the committed PMC passes profiles/r01_d_pmc_*.csv",
+                                "from the committed PMC passes profiles/r01_e_pmc_*.csv",
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                 "all_conv_launches": {
                     "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
