@@ -106,6 +106,15 @@ typedef struct miseg_conv_desc {
   int32_t collapse_value;  /* value written for the winning channel (127) */
   int32_t tile_hint;       /* 0 = choose automatically; low 4 bits = tile config 1..15,
                               | MISEG_TILE_NO_DMA forces the register-staged path (tests) */
+  /* Optional per-channel statistics of the stored bf16 output for a following training-mode
+   * BatchNormalization (fused into the epilogue instead of a second pass over the tensor):
+   * double[stats_replicas + 1][2][stats_stride], zeroed by the caller; the kernel ADDS sum(v) to
+   * [r][0][c] and sum(v*v) to [r][1][c], r = block index mod stats_replicas (the last slot is
+   * where miseg_bn_finalize puts the totals).  Needs a bf16
+   * `out`, Cout % 8 == 0 and 16-byte aligned output strides.  miseg_bn_finalize reduces it. */
+  void* stats;
+  int32_t stats_replicas;
+  int32_t stats_stride;
 } miseg_conv_desc;
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);
@@ -181,6 +190,17 @@ int miseg_collapse_u8(const float* probs, uint8_t* out, int64_t pixels, int32_t 
  * tensors, C <= 8.  sums (double[4*C], zeroed by the call) receives, per class,
  * sum(gt*pr), sum(pr), sum(gt), sum(gt*log(clip(pr/sum_c pr))).
  */
+/*
+ * Second half of miseg_bn_stats_fwd for statistics gathered by a convolution's epilogue
+ * (miseg_conv_desc.stats): reduces the replicas, then mean / biased variance, scale / shift and
+ * the moving-statistics update exactly as miseg_bn_stats_fwd does (tf.keras BatchNormalization
+ * in training mode, model_train.py:284-329).
+ */
+int miseg_bn_finalize(const double* stats, int32_t replicas, int32_t stride, int64_t pixels, int32_t C,
+                      const float* gamma, const float* beta, float* moving_mean, float* moving_var,
+                      float momentum, float eps, float* mean, float* var, float* scale, float* shift,
+                      void* stream);
+
 int miseg_loss_sums(const float* gt, const float* pr, double* sums, int64_t pixels, int32_t C,
                     void* stream);
 

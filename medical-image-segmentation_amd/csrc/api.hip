@@ -34,6 +34,8 @@ int launch_scale_shift_relu(const void*, void*, const float*, const float*, long
 int launch_collapse_u8(const float*, uint8_t*, long long, int, int, hipStream_t);
 int launch_loss_sums(const float*, const float*, double*, long long, int, hipStream_t);
 int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream);
+int launch_bn_finalize(const double*, int, int, long long, int, const float*, const float*, float*, float*,
+                       float, float, float*, float*, float*, float*, hipStream_t);
 int launch_bn_stats(const void*, long long, int, int, const float*, const float*, float*, float*, float,
                     float, float*, float*, float*, float*, double*, hipStream_t);
 int launch_input_stats(const float*, long long, const float*, float*, float*, float, float, float*,
@@ -185,6 +187,13 @@ int miseg_loss_sums(const float* gt, const float* pr, double* sums, int64_t pixe
 int miseg_conv2d_wgrad(const miseg_wgrad_desc* d, void* stream) {
   return launch_wgrad(d, (hipStream_t)stream);
 }
+int miseg_bn_finalize(const double* stats, int32_t replicas, int32_t stride, int64_t pixels, int32_t C,
+                      const float* gamma, const float* beta, float* mm, float* mv, float momentum,
+                      float eps, float* mean, float* var, float* scale, float* shift, void* stream) {
+  return launch_bn_finalize(stats, replicas, stride, pixels, C, gamma, beta, mm, mv, momentum, eps, mean,
+                            var, scale, shift, (hipStream_t)stream);
+}
+
 int miseg_bn_stats_fwd(const void* x, int64_t pixels, int32_t C, int32_t ps, const float* gamma,
                        const float* beta, float* mm, float* mv, float momentum, float eps,
                        float* mean, float* var, float* scale, float* shift, double* ws, void* stream) {

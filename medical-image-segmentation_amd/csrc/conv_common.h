@@ -54,6 +54,8 @@ struct ConvParams {
   int ntiles;   // ceil(Cout / BN)
   int vec_ok;   // strides/pointers allow 16-byte epilogue accesses
   int tiles_y, tiles_x;  // halo kernel: output patches per image
+  double* stats;         // optional per-channel sum / sum of squares of the stored bf16 output
+  int stats_rep, stats_stride;
 };
 
 // 16 zero bytes x 8: the source of LDS-DMA loads for taps that fall outside the image.
@@ -203,6 +205,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
   const bool full = co + 8 <= p.Cout && p.vec_ok;
   const bool head = p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID;
 
+  // statistics of the stored values for a following BatchNormalization (this lane's 8 channels)
+  float st_s[8], st_q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) st_s[j] = st_q[j] = 0.f;
+
   static_for<MT>([&](auto bc) __attribute__((always_inline)) {
     constexpr int b = decltype(bc)::value;
     // The region is private to this wave and a wave's LDS operations execute in order, so
@@ -288,9 +295,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
             *reinterpret_cast<float4*>(o) = make_float4(w[0], w[1], w[2], w[3]);
             *reinterpret_cast<float4*>(o + 4) = make_float4(w[4], w[5], w[6], w[7]);
           } else {
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o_off) =
-                make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]),
-                           pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
+            const uint4 pk = make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]),
+                                        pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
+            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o_off) = pk;
+            if (p.stats) {
+              const float r[8] = {bf16lo_to_f32(pk.x), bf16hi_to_f32(pk.x), bf16lo_to_f32(pk.y),
+                                  bf16hi_to_f32(pk.y), bf16lo_to_f32(pk.z), bf16hi_to_f32(pk.z),
+                                  bf16lo_to_f32(pk.w), bf16hi_to_f32(pk.w)};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                st_s[j] += r[j];
+                st_q[j] += r[j] * r[j];
+              }
+            }
           }
         }
         if (p.out2) {
@@ -339,6 +356,39 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
       }
     }
   });
+  if (p.stats) {
+    // lanes with equal lane % LPP hold the same channels: butterfly over the pixel lanes, then the
+    // first LPP lanes add the wave's totals to this block's replica
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int off = LPP; off < 64; off <<= 1) {
+        st_s[j] += __shfl_xor(st_s[j], off, 64);
+        st_q[j] += __shfl_xor(st_q[j], off, 64);
+      }
+    }
+    // block-level sums in LDS (the transposing regions are free now), then one global fp64 atomic
+    // per channel and block, issued by full waves
+    constexpr int BNB = WARPS_N * TNW;
+    float* sl = reinterpret_cast<float*>(lds);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * BNB; i += blockDim.x) sl[i] = 0.f;
+    __syncthreads();
+    if (lane < LPP) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&sl[wn * TNW + co_l + j], st_s[j]);
+        atomicAdd(&sl[BNB + wn * TNW + co_l + j], st_q[j]);
+      }
+    }
+    __syncthreads();
+    double* dst = p.stats + (long long)(blockIdx.x % p.stats_rep) * 2 * p.stats_stride;
+    for (int i = threadIdx.x; i < 2 * BNB; i += blockDim.x) {
+      const int which = i / BNB, c = tc.cout0 + (i - which * BNB);
+      const float v = sl[i];
+      if (c < p.Cout && v != 0.f) unsafeAtomicAdd(dst + which * p.stats_stride + c, (double)v);
+    }
+  }
 }
 
 template <int MT, int NT>

@@ -721,6 +721,16 @@ int validate_conv(const miseg_conv_desc* d) {
     MISEG_CHECK_ARG(((uintptr_t)d->in_scale & 15) == 0 && ((uintptr_t)d->in_shift & 15) == 0,
                     "conv: prologue vectors must be 16-byte aligned");
   }
+  if (d->stats) {
+    MISEG_CHECK_ARG(d->out && d->out_dtype == MISEG_DT_BF16 && (d->Cout & 7) == 0 && d->stats_replicas > 0 &&
+                        d->stats_stride >= d->Cout && ((uintptr_t)d->stats & 7) == 0,
+                    "conv: stats need a bf16 output, Cout % 8 == 0, replicas > 0, stride >= Cout");
+    MISEG_CHECK_ARG((d->out_pix_stride & 7) == 0 && (d->out_row_stride & 7) == 0 && (d->out_img_stride & 7) == 0 &&
+                        ((uintptr_t)d->out & 15) == 0 && !d->out2 &&
+                        (!d->residual || ((d->res_pix_stride & 7) == 0 && (d->res_row_stride & 7) == 0 &&
+                                          (d->res_img_stride & 7) == 0 && ((uintptr_t)d->residual & 15) == 0)),
+                    "conv: stats need 16-byte aligned output (and residual) strides and no second output");
+  }
   if (d->scale) MISEG_CHECK_ARG(((uintptr_t)d->scale & 15) == 0, "conv: scale misaligned");
   if (d->shift) MISEG_CHECK_ARG(((uintptr_t)d->shift & 15) == 0, "conv: shift misaligned");
   const long long M = (long long)d->N * d->Ho * d->Wo;
@@ -833,6 +843,9 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.act = d->act; p.transposed = d->transposed;
   p.inv_temperature = d->act == MISEG_ACT_SOFTMAX ? 1.f / d->temperature : 1.f;
   p.collapse_value = d->collapse_value;
+  p.stats = (double*)d->stats;
+  p.stats_rep = d->stats_replicas;
+  p.stats_stride = d->stats_stride;
   p.M = d->N * d->Ho * d->Wo;
 }
 

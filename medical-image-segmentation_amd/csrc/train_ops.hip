@@ -130,6 +130,33 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, long long co
   }
 }
 
+// sums[r][2][stride] -> out[2][C]
+__global__ void bn_reduce_replicas_kernel(const double* __restrict__ stats, int replicas, int stride,
+                                          int C, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  const int which = i / C, c = i - which * C;
+  double t = 0.0;
+  for (int r = 0; r < replicas; ++r) t += stats[((long long)r * 2 + which) * stride + c];
+  out[i] = t;
+}
+
+int launch_bn_finalize(const double* stats, int replicas, int stride, long long pixels, int C,
+                       const float* gamma, const float* beta, float* mm, float* mv, float momentum,
+                       float eps, float* mean, float* var, float* scale, float* shift, hipStream_t s) {
+  MISEG_CHECK_ARG(stats && beta && mean && var && scale && shift, "bn_finalize: null pointer");
+  MISEG_CHECK_ARG(pixels > 0 && C > 0 && replicas > 1 && stride >= C, "bn_finalize: bad extents");
+  MISEG_CHECK_ARG((mm == nullptr) == (mv == nullptr), "bn_finalize: moving stats go together");
+  // the buffer has replicas + 1 slots of [2][stride] doubles; the last one receives the totals
+  double* tot = const_cast<double*>(stats) + (long long)replicas * 2 * stride;
+  hipLaunchKernelGGL(bn_reduce_replicas_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, stats, replicas,
+                     stride, C, tot);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, tot, pixels, C, gamma,
+                     beta, mm, mv, momentum, eps, mean, var, scale, shift);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
 int launch_bn_stats(const void* x, long long pixels, int C, int ps, const float* gamma,
                     const float* beta, float* mm, float* mv, float momentum, float eps, float* mean,
                     float* var, float* scale, float* shift, double* ws, hipStream_t s) {

@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("out_dtype", C.c_int32), ("res_dtype", C.c_int32), ("act", C.c_int32),
         ("transposed", C.c_int32), ("temperature", C.c_float), ("collapse_value", C.c_int32),
         ("tile_hint", C.c_int32),
+        ("stats", C.c_void_p), ("stats_replicas", C.c_int32), ("stats_stride", C.c_int32),
     ]
 
 
@@ -74,6 +75,8 @@ SIGNATURES = {
     "miseg_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), _VP]),
     "miseg_bn_stats_fwd": (C.c_int, [_VP, _I64, _I32, _I32, _FP, _FP, _FP, _FP, C.c_float, C.c_float,
                                      _FP, _FP, _FP, _FP, _VP, _VP]),
+    "miseg_bn_finalize": (C.c_int, [_VP, _I32, _I32, _I64, _I32, _FP, _FP, _FP, _FP, C.c_float, C.c_float,
+                                    _FP, _FP, _FP, _FP, _VP]),
     "miseg_input_stats_fwd": (C.c_int, [_FP, _I64, _FP, _FP, _FP, C.c_float, C.c_float, _FP, _FP, _FP,
                                         _FP, _VP, _VP]),
     "miseg_bn_relu_bwd_reduce": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, _FP, _FP, _FP, _FP,

@@ -25,6 +25,9 @@ import torch
 from . import lib as L
 
 
+STAT_REPLICAS = 32
+
+
 def _c32(c):
     return (c + 31) // 32 * 32
 
@@ -194,6 +197,10 @@ class Trainer:
                 cp = max(c, 8)
                 self.bn_state[l.name] = {k: torch.zeros(cp, device=dev) for k in ("mean", "var", "scale", "shift")}
                 self.bn_state[l.name]["ws"] = torch.zeros(2 * cp, dtype=torch.float64, device=dev)
+                # statistics gathered by the producing convolution's epilogue: STAT_REPLICAS slots the
+                # blocks spread their atomics over, plus one for the totals
+                self.bn_state[l.name]["fused"] = torch.zeros((STAT_REPLICAS + 1) * 2 * _c32(c),
+                                                             dtype=torch.float64, device=dev)
         self.stem_mask = None
         self.set_weights(weights)
         self.layer_lo = {}
@@ -320,8 +327,10 @@ class Trainer:
         return buf.slice(c0, c)
 
     def conv(self, x, wptr, cout, kh, kw, sy, sx, py, px, out, ho, wo, bias=None, transposed=False,
-             out_view=None, act=L.ACT_NONE, probs=None, temperature=1.0, residual=None):
-        """out_view: (ptr, pix, row, img) to address a strided lattice; default = dense `out`."""
+             out_view=None, act=L.ACT_NONE, probs=None, temperature=1.0, residual=None, stats=None):
+        """out_view: (ptr, pix, row, img) to address a strided lattice; default = dense `out`.
+        stats: zeroed fp64 buffer of (STAT_REPLICAS + 1) * 2 * _c32(cout) entries that receives the
+        per-channel sum and sum of squares of the stored output (for a following BatchNormalization)."""
         d = L.ConvDesc()
         d.inp, d.weight = x.ptr, wptr
         d.N, d.H, d.W, d.Cin = x.n, x.h, x.w, _c32(x.c)
@@ -349,7 +358,23 @@ class Trainer:
         d.act = act
         d.transposed = 1 if transposed else 0
         d.temperature = temperature
+        if stats is not None:
+            d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), STAT_REPLICAS, _c32(cout)
         L.check(self.lib.miseg_conv2d_fwd(C.byref(d), self.stream()))
+
+    def _stats_for(self, name, cout):
+        """The statistics buffer of the BatchNormalization that is the only consumer of convolution
+        `name` (zeroed, and remembered so that the BatchNormalization only finalises), else None."""
+        cons = self.consumers.get(name, [])
+        if len(cons) != 1 or cout % 8:
+            return None
+        bn = self.g.layers[cons[0]]
+        if bn.cls != "BatchNormalization" or bn.name in self.frozen or bn.name not in self.bn_state:
+            return None
+        buf = self.bn_state[bn.name]["fused"]
+        buf.zero_()
+        self.fused_stats.add(bn.name)
+        return buf
 
     def wgrad(self, x, dy_ptr, dy_strides, dw_ptr, cin, cout, kh, kw, sy, sx, py, px, ho, wo,
               x_geom=None):
@@ -436,6 +461,7 @@ class Trainer:
         self.acts = {}
         self.saved = {}
         self.concat_bufs = {}
+        self.fused_stats = set()
         n = self.n
         self.x_in = x.contiguous()
         for name in self.order:
@@ -479,13 +505,14 @@ class Trainer:
                     continue
                 out = self.new_out(name, l.out.h, l.out.w, co)
                 self.conv(xin, self.wptr(name), co, k, k, stride, stride, pad, pad, out, l.out.h, l.out.w,
-                          bias=bias)
+                          bias=bias, stats=self._stats_for(name, co))
                 self.acts[name] = out
                 self.saved[name] = (xin, pad)
             elif cls == "Conv2DTranspose":
                 xin = self.acts[l.inbound[0]]
                 out = self.new_out(name, l.out.h, l.out.w, l.out.c)
-                self.conv(xin, self.wptr(name), l.out.c, 2, 2, 1, 1, 0, 0, out, xin.h, xin.w, transposed=True)
+                self.conv(xin, self.wptr(name), l.out.c, 2, 2, 1, 1, 0, 0, out, xin.h, xin.w, transposed=True,
+                          stats=self._stats_for(name, l.out.c))
                 self.acts[name] = out
                 self.saved[name] = (xin, 0)
             elif cls == "BatchNormalization":
@@ -496,6 +523,13 @@ class Trainer:
                 gamma = self.view(name, "gamma").data_ptr() if l.config["scale"] else None
                 if name in self.frozen:
                     self._frozen_bn(l, s)
+                elif name in self.fused_stats:
+                    L.check(lib.miseg_bn_finalize(
+                        s["fused"].data_ptr(), STAT_REPLICAS, _c32(c), xin.pixels, c, gamma,
+                        self.view(name, "beta").data_ptr(),
+                        mm.data_ptr() if mm is not None else None, mv.data_ptr() if mv is not None else None,
+                        l.config["momentum"], l.config["epsilon"], s["mean"].data_ptr(), s["var"].data_ptr(),
+                        s["scale"].data_ptr(), s["shift"].data_ptr(), st))
                 else:
                     L.check(lib.miseg_bn_stats_fwd(
                         xin.ptr, xin.pixels, c, xin.pix, gamma, self.view(name, "beta").data_ptr(),
@@ -595,6 +629,9 @@ class Trainer:
         d.out = out.ptr
         d.out_pix_stride, d.out_row_stride, d.out_img_stride = out.pix, out.pix * (w // 2), out.pix * (w // 2) * (h // 2)
         d.temperature = 1.0
+        stats = self._stats_for(l.name, 64)
+        if stats is not None:
+            d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), STAT_REPLICAS, 64
         L.check(lib.miseg_conv2d_fwd(C.byref(d), st))
         self.acts[l.name] = out
         self.saved[l.name] = (padded, src)

@@ -308,3 +308,60 @@ def test_adam_keras_form(env):
     np.testing.assert_allclose(v.cpu().numpy(), v1, rtol=2e-5, atol=1e-10)
     np.testing.assert_allclose(p.cpu().numpy(), p1, rtol=2e-5, atol=1e-6)
     np.testing.assert_array_equal(pb.float().cpu().numpy(), bf16_round(p.cpu().numpy()))
+
+
+@pytest.mark.parametrize("case", [(2, 16, 40, 64, 128, 3, False), (1, 9, 33, 64, 64, 3, False),
+                                  (2, 12, 20, 32, 32, 3, False), (1, 8, 16, 64, 32, 1, False),
+                                  (2, 8, 24, 64, 64, 4, True), (1, 10, 20, 128, 160, 3, False)])
+def test_conv_epilogue_statistics(env, case):
+    """miseg_conv_desc.stats: per-channel sum / sum of squares of the STORED bf16 output, spread over
+    replicas, then miseg_bn_finalize == miseg_bn_stats_fwd on the same tensor (mean/var to fp32
+    round-off; the fused path adds the same bf16 values in a different order)."""
+    L, lib, dev = env
+    n, h, w, cin, cout, k, transposed = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = torch.from_numpy(rng.normal(0, 1, (n, h, w, cin)).astype(np.float32)).to(torch.bfloat16).to(dev)
+    R = 8
+    d = L.ConvDesc()
+    if transposed:
+        wt = torch.from_numpy(rng.normal(0, 0.1, (4, cout, 2, 2, cin)).astype(np.float32)).to(torch.bfloat16).to(dev)
+        oh, ow = 2 * h, 2 * w
+        d.Ho, d.Wo, d.KH, d.KW, d.pad_y, d.pad_x, d.transposed = h, w, 2, 2, 0, 0, 1
+    else:
+        wt = torch.from_numpy(rng.normal(0, 0.1, (cout, k, k, cin)).astype(np.float32)).to(torch.bfloat16).to(dev)
+        oh, ow = h, w
+        d.Ho, d.Wo, d.KH, d.KW, d.pad_y, d.pad_x = h, w, k, k, (k - 1) // 2, (k - 1) // 2
+    out = torch.zeros((n, oh, ow, cout), dtype=torch.bfloat16, device=dev)
+    stats = torch.zeros((R + 1, 2, cout), dtype=torch.float64, device=dev)
+    d.inp, d.weight, d.out = x.data_ptr(), wt.data_ptr(), out.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Cout = n, h, w, cin, cout
+    d.stride_y = d.stride_x = 1
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin, cin * w, cin * w * h
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * ow, cout * ow * oh
+    d.temperature = 1.0
+    d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), R, cout
+    L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+    torch.cuda.synchronize()
+    o = out.double().reshape(-1, cout)
+    got = stats[:R].sum(0).cpu().numpy()
+    np.testing.assert_allclose(got[0], o.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(got[1], (o * o).sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    # finalize == the stand-alone statistics kernel
+    beta = torch.zeros(cout, device=dev)
+    res = []
+    for fused in (True, False):
+        mean, var, scale, shift = (torch.zeros(cout, device=dev) for _ in range(4))
+        mm, mv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+        if fused:
+            L.check(lib.miseg_bn_finalize(stats.data_ptr(), R, cout, o.shape[0], cout, None, beta.data_ptr(),
+                                          mm.data_ptr(), mv.data_ptr(), 0.99, 1e-3, mean.data_ptr(),
+                                          var.data_ptr(), scale.data_ptr(), shift.data_ptr(), None))
+        else:
+            ws = torch.zeros(2 * cout, dtype=torch.float64, device=dev)
+            L.check(lib.miseg_bn_stats_fwd(out.data_ptr(), o.shape[0], cout, cout, None, beta.data_ptr(),
+                                           mm.data_ptr(), mv.data_ptr(), 0.99, 1e-3, mean.data_ptr(),
+                                           var.data_ptr(), scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), None))
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy() for t in (mean, var, scale, shift, mm, mv)])
+    for a, b in zip(*res):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
