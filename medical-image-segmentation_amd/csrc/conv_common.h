@@ -368,25 +368,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
       }
     }
     // block-level sums in LDS (the transposing regions are free now), then one global fp64 atomic
-    // per channel and block, issued by full waves
+    // per channel and block, issued by full waves.  The LDS sums are fp64 as well: the order in
+    // which waves arrive must not show in the fp32 statistics derived from them.
     constexpr int BNB = WARPS_N * TNW;
-    float* sl = reinterpret_cast<float*>(lds);
+    double* sl = reinterpret_cast<double*>(lds);
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * BNB; i += blockDim.x) sl[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * BNB; i += blockDim.x) sl[i] = 0.0;
     __syncthreads();
     if (lane < LPP) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        atomicAdd(&sl[wn * TNW + co_l + j], st_s[j]);
-        atomicAdd(&sl[BNB + wn * TNW + co_l + j], st_q[j]);
+        unsafeAtomicAdd(&sl[wn * TNW + co_l + j], (double)st_s[j]);
+        unsafeAtomicAdd(&sl[BNB + wn * TNW + co_l + j], (double)st_q[j]);
       }
     }
     __syncthreads();
     double* dst = p.stats + (long long)(blockIdx.x % p.stats_rep) * 2 * p.stats_stride;
     for (int i = threadIdx.x; i < 2 * BNB; i += blockDim.x) {
       const int which = i / BNB, c = tc.cout0 + (i - which * BNB);
-      const float v = sl[i];
-      if (c < p.Cout && v != 0.f) unsafeAtomicAdd(dst + which * p.stats_stride + c, (double)v);
+      const double v = sl[i];
+      if (c < p.Cout && v != 0.0) unsafeAtomicAdd(dst + which * p.stats_stride + c, v);
     }
   }
 }

@@ -17,6 +17,7 @@ pass is still running).
 """
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -77,7 +78,7 @@ class Seg:
 
 
 class Trainer:
-    def __init__(self, graph, weights, batch, device="cuda:0", learning_rate=1e-3, beta_1=0.9,
+    def __init__(self, graph, weights, batch, device="cuda:0", learning_rate=1e-3, beta_1=0.9, side_stream=True,
                  beta_2=0.999, epsilon=1e-7, loss="cce_dice", world_size=1, bucket_mb=25,
                  freeze_encoder=False):
         if not torch.cuda.is_available():
@@ -85,6 +86,10 @@ class Trainer:
         self.lib = L.load()
         self.dev = torch.device(device)
         torch.cuda.set_device(self.dev)
+        # Weight gradients are off the critical path of the backward pass (nothing downstream reads
+        # them before the optimiser / the all-reduce): they run on a second stream, next to the
+        # data-gradient chain, and fill the ramps and tails of its launches.
+        self.side = torch.cuda.Stream(self.dev) if side_stream else None
         L.check(self.lib.miseg_device_check())
         self.g = graph
         self.n = batch
@@ -366,7 +371,7 @@ class Trainer:
         """The statistics buffer of the BatchNormalization that is the only consumer of convolution
         `name` (zeroed, and remembered so that the BatchNormalization only finalises), else None."""
         cons = self.consumers.get(name, [])
-        if len(cons) != 1 or cout % 8:
+        if len(cons) != 1 or cout % 8 or os.environ.get("MISEG_NO_FUSED_STATS"):
             return None
         bn = self.g.layers[cons[0]]
         if bn.cls != "BatchNormalization" or bn.name in self.frozen or bn.name not in self.bn_state:
@@ -377,7 +382,9 @@ class Trainer:
         return buf
 
     def wgrad(self, x, dy_ptr, dy_strides, dw_ptr, cin, cout, kh, kw, sy, sx, py, px, ho, wo,
-              x_geom=None):
+              x_geom=None, dy_t=None):
+        """dy_t: the tensor behind dy_ptr; it is kept from being recycled until the side stream has
+        read it."""
         d = L.WgradDesc()
         d.x, d.dy, d.dw = x.ptr, dy_ptr, dw_ptr
         if x_geom is None:
@@ -388,7 +395,22 @@ class Trainer:
         d.Cin, d.Ho, d.Wo, d.Cout = cin, ho, wo, cout
         d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
         d.dy_pix, d.dy_row, d.dy_img = dy_strides
-        L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.stream()))
+        if self.side is None:
+            L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.stream()))
+            return
+        main = torch.cuda.current_stream(self.dev)
+        ev = torch.cuda.Event()
+        ev.record(main)                       # dy (and everything before it) is ready
+        self.side.wait_event(ev)
+        L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.side.cuda_stream))
+        for t in (dy_t, getattr(x, "t", None)):
+            if t is not None:
+                t.record_stream(self.side)
+
+    def _join_side(self):
+        """The main stream waits for the weight gradients launched so far."""
+        if self.side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
     def add_into(self, a, b, c=None, out=None):
         """returns a + b (bf16) as a new tensor (or in `out`)."""
@@ -674,6 +696,8 @@ class Trainer:
     def backward(self, loss_scale=1.0):
         g, lib, st, n = self.g, self.lib, self.stream(), self.n
         self.G.zero_()
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
         grads = {}
         self.grad_log = {} if self.keep_grads else None
         self.accum_log, self.accum_final = {}, {}
@@ -773,6 +797,7 @@ class Trainer:
             else:
                 raise NotImplementedError("backward of %s" % cls)
             self._grads_final(name)
+        self._join_side()
         if self.buckets is not None:
             self.buckets.flush()
 
@@ -794,7 +819,8 @@ class Trainer:
             padded, src = self.saved[name]
             h, w = self.H, self.W
             self.wgrad(Act(padded, 4), dy.ptr, dy_str, dw_ptr, 32, co, 7, 1, 2, 1, 0, 0, h // 2, w // 2,
-                       x_geom=(n, h + 6, w // 2, 8, (w + 8) * 4, (h + 6) * (w + 8) * 4))
+                       x_geom=(n, h + 6, w // 2, 8, (w + 8) * 4, (h + 6) * (w + 8) * 4), dy_t=dy.t)
+            self._join_side()
             gk = self.gview(name, "kernel")
             srcl = self.g.layers[src]
             if srcl.cls == "BatchNormalization":
@@ -811,7 +837,7 @@ class Trainer:
         xin, pad = self.saved[name]
         cin = _c32(xin.c)
         self.wgrad(xin, dy.ptr, dy_str, dw_ptr, cin, (co + 7) // 8 * 8, k, k, stride, stride, pad, pad,
-                   l.out.h, l.out.w)
+                   l.out.h, l.out.w, dy_t=dy.t)
         # data gradient
         src_name = self._src(l.inbound[0])[0]
         if self.g.layers[src_name].cls == "InputLayer":
@@ -853,7 +879,7 @@ class Trainer:
                 dyp = dy.ptr + 2 * (a * dy.pix * dy.w + b * dy.pix)
                 self.wgrad(xin, dyp, (2 * dy.pix, 2 * dy.pix * dy.w, dy.pix * dy.w * dy.h),
                            self.G.data_ptr() + 4 * (seg.off + (a * 2 + b) * per_phase), cin, co, 2, 2, 1, 1,
-                           1 - a, 1 - b, xin.h, xin.w)
+                           1 - a, 1 - b, xin.h, xin.w, dy_t=dy.t)
         src_name = l.inbound[0]
         wt = self.dgrad_weight(l)[0]
         dyv = Act(dy.t, _c32(co), dy.c0)
@@ -872,7 +898,14 @@ class Trainer:
             return
         lo = self.layer_lo.get(name)
         if lo is not None:
+            if self.hi_pending(lo):
+                self._join_side()             # the bucket about to leave includes side-stream gradients
             self.buckets.ready(lo)
+
+    def hi_pending(self, lo):
+        """Would announcing `lo` send a bucket now?"""
+        b = self.buckets
+        return b.hi - max(0, min(lo, b.hi)) >= b.bucket
 
     # ------------------------------------------------------------------ optimiser
     def adam_step(self):
