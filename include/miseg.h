@@ -140,6 +140,11 @@ int miseg_conv_c32_head_fwd(const miseg_conv_desc* body, const miseg_conv_desc* 
  */
 int miseg_prep_input(const float* in, void* out, const float* scale, const float* shift,
                      int32_t N, int32_t H, int32_t W, void* stream);
+/* Training variant: the fourth, otherwise dead, channel holds 1 inside the image, so that the stem's
+ * weight gradient for that channel is the per-tap sum of dY from which the beta gradient of the
+ * input BatchNormalization (`bn_data`) follows without a data-gradient pass through the stem. */
+int miseg_prep_input_indicator(const float* in, void* out, const float* scale, const float* shift,
+                               int32_t N, int32_t H, int32_t W, void* stream);
 
 /*
  * ZeroPadding2D(1) + MaxPooling2D(3, strides 2) on a non-negative bf16 tensor,

@@ -22,7 +22,7 @@ int validate_conv(const miseg_conv_desc* d);
 void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len);
 int validate_conv_c32_head(const miseg_conv_desc* body, const miseg_conv_desc* head);
 int launch_conv_c32_head(const miseg_conv_desc* body, const miseg_conv_desc* head, hipStream_t stream);
-int launch_prep_input(const float*, void*, const float*, const float*, int, int, int, hipStream_t);
+int launch_prep_input(const float*, void*, const float*, const float*, int, int, int, hipStream_t, bool indicator = false);
 int launch_maxpool3x3s2(const void*, void*, const float*, const float*, int, int, int, int, int,
                         int, hipStream_t);
 int launch_avgpool2x2(const void*, void*, int, int, int, int, int, int, hipStream_t);
@@ -143,6 +143,11 @@ int miseg_conv_c32_head_fwd(const miseg_conv_desc* body, const miseg_conv_desc* 
 int miseg_prep_input(const float* in, void* out, const float* scale, const float* shift, int32_t N,
                      int32_t H, int32_t W, void* stream) {
   return launch_prep_input(in, out, scale, shift, N, H, W, (hipStream_t)stream);
+}
+
+int miseg_prep_input_indicator(const float* in, void* out, const float* scale, const float* shift,
+                               int32_t N, int32_t H, int32_t W, void* stream) {
+  return launch_prep_input(in, out, scale, shift, N, H, W, (hipStream_t)stream, true);
 }
 
 int miseg_maxpool3x3s2_fwd(const void* in, void* out, const float* scale, const float* shift,

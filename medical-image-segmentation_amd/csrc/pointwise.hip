@@ -17,6 +17,9 @@ static inline int grid_for(long long work, int block = 256) {
 // ---------------------------------------------------------------------------------
 // fp32 [N][H][W][3] -> bf16 [N][H+6][W+8][4], image at (3,3), zero elsewhere
 // ---------------------------------------------------------------------------------
+// IND: channel 3 = 1 inside the image (the indicator the training path uses to obtain the input
+// BatchNorm's beta gradient from the stem's weight gradient), else 0 everywhere
+template <bool IND>
 __global__ void prep_input_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   int N, int H, int W) {
@@ -35,20 +38,24 @@ __global__ void prep_input_kernel(const float* __restrict__ in, bf16_t* __restri
     if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
       const float* px = in + (((long long)n * H + y) * W + x) * 3;
       v.x = pack_bf16x2(px[0] * s0 + t0, px[1] * s1 + t1);
-      v.y = pack_bf16x2(px[2] * s2 + t2, 0.f);
+      v.y = pack_bf16x2(px[2] * s2 + t2, IND ? 1.f : 0.f);
     }
     *reinterpret_cast<uint2*>(out + i * 4) = v;
   }
 }
 
 int launch_prep_input(const float* in, void* out, const float* scale, const float* shift, int N,
-                      int H, int W, hipStream_t s) {
+                      int H, int W, hipStream_t s, bool indicator) {
   MISEG_CHECK_ARG(in && out && scale && shift, "prep_input: null pointer");
   MISEG_CHECK_ARG(N > 0 && H > 0 && W > 0 && (W & 1) == 0 && (H & 1) == 0,
                   "prep_input: H and W must be positive and even");
   const long long total = (long long)N * (H + 6) * (W + 8);
-  hipLaunchKernelGGL(prep_input_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, (bf16_t*)out,
-                     scale, shift, N, H, W);
+  if (indicator)
+    hipLaunchKernelGGL(prep_input_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, in, (bf16_t*)out,
+                       scale, shift, N, H, W);
+  else
+    hipLaunchKernelGGL(prep_input_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, in, (bf16_t*)out,
+                       scale, shift, N, H, W);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
 }

@@ -65,6 +65,7 @@ SIGNATURES = {
     "miseg_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _VP]),
     "miseg_conv_c32_head_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _VP]),
     "miseg_prep_input": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
+    "miseg_prep_input_indicator": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
     "miseg_maxpool3x3s2_fwd": (C.c_int, [_VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_avgpool2x2_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_upsample_nearest_fwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),

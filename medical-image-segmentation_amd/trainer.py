@@ -636,11 +636,10 @@ class Trainer:
         else:
             sc = torch.ones(8, device=self.dev)
             sh = torch.zeros(8, device=self.dev)
-        L.check(lib.miseg_prep_input(self.x_in.data_ptr(), padded.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                                     n, h, w, st))
         # channel 3 = indicator of "inside the image": the stem's weight gradient for that (dead)
         # channel then equals the per-tap sums of dY that the input BatchNorm's beta gradient needs
-        padded[:, 3:3 + h, 3:3 + w, 3] = 1.0
+        L.check(lib.miseg_prep_input_indicator(self.x_in.data_ptr(), padded.data_ptr(), sc.data_ptr(),
+                                               sh.data_ptr(), n, h, w, st))
         out = self.new_out(l.name, h // 2, w // 2, 64)
         d = L.ConvDesc()
         d.inp, d.weight = padded.data_ptr(), self.wptr(l.name)
