@@ -236,7 +236,7 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
 }
 
 template <int KH, int KW, int CO_T, int CI_T>
-__global__ __launch_bounds__(256, (KH * KW == 9 && CO_T == 64 && CI_T == 64) ? 1 : 2) void wgrad_halo_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradParams p) {
   constexpr int TH = 8, TW = 32;
   constexpr int HR = TH + KH - 1, HWD = TW + KW - 1, HP = HR * HWD;
   constexpr int XRB = CI_T * 2, YRB = CO_T * 2;          // LDS bytes per pixel row
@@ -285,17 +285,37 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && CO_T == 64 && CI_T == 64) ? 1
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
   };
-  auto xfrag = [&](int row0) __attribute__((always_inline)) {       // 16 halo pixels from row0
+  // Fragment addresses = a per-lane base + a compile-time offset.  A fragment's first LDS row is
+  // r = row0 + kgrp; the XOR swizzle only looks at bit 1 of r, and 4 divides every run-time part of
+  // row0 (16 * w, ya * HWD with ya in {0, 4} and HWD even, TW = 32), so the swizzled offset depends
+  // on the lane and on (compile-time part of row0) mod 4 only: four bases for X, one for dY, and
+  // the rest of the address is an immediate (the second half of a fragment is 4 rows further,
+  // which leaves bit 1 of the row unchanged).
+  const int run_w = WK == 1 ? 0 : (WK == 2 ? kpart : (kpart & 1));         // column window, if run-time
+  const int run_ya = WK == 4 ? (kpart >> 1) * (TH / 2) : 0;
+  const unsigned char* xl[4];
+  {
     const int col = wn * 32 + cgrp, chunk = col >> 3, within = (col & 7) * 2;
-    const int r0 = row0 + kgrp, r1 = r0 + 4;
-    return read2(xt + r0 * XRB + xswz(r0, chunk) * 16 + within,
-                 xt + r1 * XRB + xswz(r1, chunk) * 16 + within);
-  };
-  auto yfrag = [&](int row0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      xl[m] = xt + (kgrp + run_ya * HWD + run_w * 16) * XRB + xswz(m + kgrp, chunk) * 16 + within;
+  }
+  const unsigned char* yl;
+  {
     const int col = wm * 32 + cgrp, chunk = col >> 3, within = (col & 7) * 2;
-    const int r0 = row0 + kgrp, r1 = r0 + 4;
-    return read2(yt + r0 * YRB + yswz(r0, chunk) * 16 + within,
-                 yt + r1 * YRB + yswz(r1, chunk) * 16 + within);
+    yl = yt + (kgrp + run_ya * TW + run_w * 16) * YRB + yswz(kgrp, chunk) * 16 + within;
+  }
+  // row0c: the compile-time part of the fragment's first pixel row
+  auto xfrag = [&](auto row0c) __attribute__((always_inline)) {
+    constexpr int row0 = decltype(row0c)::value;
+    const unsigned char* a = xl[row0 & 3] + row0 * XRB;
+    return read2(a, a + 4 * XRB);
+  };
+  auto yfrag = [&](auto row0c) __attribute__((always_inline)) {
+    constexpr int row0 = decltype(row0c)::value;
+    static_assert((row0 & 3) == 0, "dY fragments start at multiples of 16 pixels");
+    const unsigned char* a = yl + row0 * YRB;
+    return read2(a, a + 4 * YRB);
   };
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -338,18 +358,20 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && CO_T == 64 && CI_T == 64) ? 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    auto roll = [&](auto rows_c, int w, int ya) __attribute__((always_inline)) {
+    // w_c: the column window when it is a compile-time choice (WK == 1), else 0 (folded into the bases)
+    auto roll = [&](auto rows_c, auto w_c) __attribute__((always_inline)) {
       constexpr int ROWS = decltype(rows_c)::value;
+      constexpr int w = decltype(w_c)::value;
       bf16x8 xf[KH][KW];
       wg_static_for<ROWS + KH - 1>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;           // halo row ya + i
         wg_static_for<KW>([&](auto kc) __attribute__((always_inline)) {
           constexpr int kx = decltype(kc)::value;
-          xf[i % KH][kx] = xfrag((ya + i) * HWD + w * 16 + kx);
+          xf[i % KH][kx] = xfrag(std::integral_constant<int, i * HWD + w * 16 + kx>{});
         });
         if constexpr (i >= KH - 1) {
           constexpr int y = i - (KH - 1);
-          const bf16x8 yf = yfrag((ya + y) * TW + w * 16);
+          const bf16x8 yf = yfrag(std::integral_constant<int, y * TW + w * 16>{});
           wg_static_for<KH>([&](auto kyc) __attribute__((always_inline)) {
             constexpr int ky = decltype(kyc)::value;
             wg_static_for<KW>([&](auto kc) __attribute__((always_inline)) {
@@ -362,12 +384,12 @@ __global__ __launch_bounds__(256, (KH * KW == 9 && CO_T == 64 && CI_T == 64) ? 1
       });
     };
     if constexpr (WK == 1) {
-      roll(std::integral_constant<int, TH>{}, 0, 0);
-      roll(std::integral_constant<int, TH>{}, 1, 0);
+      roll(std::integral_constant<int, TH>{}, std::integral_constant<int, 0>{});
+      roll(std::integral_constant<int, TH>{}, std::integral_constant<int, 1>{});
     } else if constexpr (WK == 2) {
-      roll(std::integral_constant<int, TH>{}, kpart, 0);
+      roll(std::integral_constant<int, TH>{}, std::integral_constant<int, 0>{});
     } else {
-      roll(std::integral_constant<int, TH / 2>{}, kpart & 1, (kpart >> 1) * (TH / 2));
+      roll(std::integral_constant<int, TH / 2>{}, std::integral_constant<int, 0>{});
     }
   }
 
