@@ -316,6 +316,24 @@ int miseg_loss_grad(const float* gt, const float* pr, const double* sums, void* 
                     float temperature, int32_t use_cce, int32_t use_dice, void* stream);
 
 /*
+ * The same for every loss the reference can select (model_train.py:172-177, utils/model.py:92-95):
+ * flags = 1 (categorical_crossentropy) | 2 (dice_loss) | 4 (focal_loss: -gt alpha (1-pr)^gamma
+ * log(clip(pr)), mean over all elements; segmentation_models' defaults are alpha 0.25, gamma 2).
+ * C == 1 is the sigmoid head (classes == 1, utils/model.py:180): dz = g pr (1 - pr).
+ */
+#define MISEG_LOSS_CCE 1
+#define MISEG_LOSS_DICE 2
+#define MISEG_LOSS_FOCAL 4
+int miseg_loss_grad_ex(const float* gt, const float* pr, const double* sums, void* dlogits,
+                       int64_t pixels, int32_t C, int32_t out_stride, float loss_scale,
+                       float temperature, int32_t flags, float alpha, float gamma, void* stream);
+
+/* miseg_loss_sums plus a fifth row, sum(gt * alpha * (1 - q)^gamma * log q), q = clip(pr, 1e-7,
+ * 1 - 1e-7): sums is double[5*C]. */
+int miseg_loss_sums_focal(const float* gt, const float* pr, double* sums, int64_t pixels, int32_t C,
+                          float alpha, float gamma, void* stream);
+
+/*
  * Keras-form Adam on flat fp32 buffers:  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;
  * p -= lr_t * m / (sqrt(v) + eps),  lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (computed by the caller);
  * grad_scale multiplies g first.  Also writes the bf16 working copy of p when p_bf16 != NULL.

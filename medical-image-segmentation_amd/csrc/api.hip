@@ -63,6 +63,9 @@ int launch_upsample_bilinear2x_bwd(const void*, void*, int, int, int, int, int, 
 int launch_copy_channels(const void*, const void*, void*, long long, int, int, int, int, hipStream_t);
 int launch_loss_grad(const float*, const float*, const double*, void*, long long, int, int, float,
                      float, int, int, hipStream_t);
+int launch_loss_grad_ex(const float*, const float*, const double*, void*, long long, int, int, float, float,
+                        int, float, float, hipStream_t);
+int launch_loss_sums_focal(const float*, const float*, double*, long long, int, float, float, hipStream_t);
 int launch_adam(float*, float*, float*, const float*, void*, long long, float, float, float, float,
                 float, hipStream_t);
 
@@ -279,6 +282,16 @@ int miseg_loss_grad(const float* gt, const float* pr, const double* sums, void* 
                     float temperature, int32_t use_cce, int32_t use_dice, void* stream) {
   return launch_loss_grad(gt, pr, sums, dlogits, pixels, C, out_stride, loss_scale, temperature,
                           use_cce, use_dice, (hipStream_t)stream);
+}
+int miseg_loss_grad_ex(const float* gt, const float* pr, const double* sums, void* dlogits,
+                       int64_t pixels, int32_t C, int32_t out_stride, float loss_scale,
+                       float temperature, int32_t flags, float alpha, float gamma, void* stream) {
+  return launch_loss_grad_ex(gt, pr, sums, dlogits, pixels, C, out_stride, loss_scale, temperature, flags,
+                             alpha, gamma, (hipStream_t)stream);
+}
+int miseg_loss_sums_focal(const float* gt, const float* pr, double* sums, int64_t pixels, int32_t C,
+                          float alpha, float gamma, void* stream) {
+  return launch_loss_sums_focal(gt, pr, sums, pixels, C, alpha, gamma, (hipStream_t)stream);
 }
 int miseg_adam_step(float* p, float* m, float* v, const float* g, void* p_bf16, int64_t count,
                     float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream) {

@@ -341,12 +341,15 @@ int launch_collapse_u8(const float* probs, uint8_t* out, long long pixels, int C
 // ---------------------------------------------------------------------------------
 // loss / metric sums: per class sum(gt*pr), sum(pr), sum(gt), sum(gt*log(clip(pr/sum pr)))
 // ---------------------------------------------------------------------------------
-template <int C>
+// FOCAL: a fifth row, sum(gt * alpha * (1 - q)^gamma * log q) with q = clip(pr) (no renormalisation:
+// segmentation_models categorical_focal_loss)
+template <int C, bool FOCAL>
 __global__ void loss_sums_kernel(const float* __restrict__ gt, const float* __restrict__ pr,
-                                 double* __restrict__ sums, long long pixels) {
-  float acc[4 * C];
+                                 double* __restrict__ sums, long long pixels, float alpha, float gamma) {
+  constexpr int R = FOCAL ? 5 : 4;
+  float acc[R * C];
 #pragma unroll
-  for (int j = 0; j < 4 * C; ++j) acc[j] = 0.f;
+  for (int j = 0; j < R * C; ++j) acc[j] = 0.f;
   // per-thread fp32 partials over at most a few thousand pixels, then fp64 atomics
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < pixels;
        i += (long long)gridDim.x * blockDim.x) {
@@ -365,40 +368,57 @@ __global__ void loss_sums_kernel(const float* __restrict__ gt, const float* __re
       acc[C + j] += p[j];
       acc[2 * C + j] += g[j];
       acc[3 * C + j] += g[j] * __logf(q);
+      if (FOCAL) {
+        const float qf = fminf(fmaxf(p[j], 1e-7f), 1.f - 1e-7f);
+        acc[4 * C + j] += g[j] * alpha * __powf(1.f - qf, gamma) * __logf(qf);
+      }
     }
   }
-  __shared__ double red[4 * C];
-  if (threadIdx.x < 4 * C) red[threadIdx.x] = 0.0;
+  __shared__ double red[R * C];
+  if (threadIdx.x < R * C) red[threadIdx.x] = 0.0;
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 4 * C; ++j) {
+  for (int j = 0; j < R * C; ++j) {
     float v = acc[j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&red[j], (double)v);
   }
   __syncthreads();
-  if (threadIdx.x < 4 * C) atomicAdd(&sums[threadIdx.x], red[threadIdx.x]);
+  if (threadIdx.x < R * C) atomicAdd(&sums[threadIdx.x], red[threadIdx.x]);
+}
+
+template <bool FOCAL>
+static int launch_loss_sums_t(const float* gt, const float* pr, double* sums, long long pixels, int C,
+                              float alpha, float gamma, hipStream_t s) {
+  MISEG_CHECK_ARG(gt && pr && sums, "loss_sums: null pointer");
+  MISEG_CHECK_ARG(pixels > 0 && C >= 1 && C <= 8, "loss_sums: need 1 <= C <= 8");
+  MISEG_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * (FOCAL ? 5 : 4) * C, s));
+  const dim3 grid(grid_for(pixels)), block(256);
+#define MISEG_LS(CC)                                                                                 \
+  case CC:                                                                                           \
+    hipLaunchKernelGGL((loss_sums_kernel<CC, FOCAL>), grid, block, 0, s, gt, pr, sums, pixels, alpha, \
+                       gamma);                                                                       \
+    break;
+  switch (C) {
+    MISEG_LS(1) MISEG_LS(2) MISEG_LS(3) MISEG_LS(4) MISEG_LS(5) MISEG_LS(6) MISEG_LS(7)
+    default:
+      hipLaunchKernelGGL((loss_sums_kernel<8, FOCAL>), grid, block, 0, s, gt, pr, sums, pixels, alpha, gamma);
+  }
+#undef MISEG_LS
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
 }
 
 int launch_loss_sums(const float* gt, const float* pr, double* sums, long long pixels, int C,
                      hipStream_t s) {
-  MISEG_CHECK_ARG(gt && pr && sums, "loss_sums: null pointer");
-  MISEG_CHECK_ARG(pixels > 0 && C >= 1 && C <= 8, "loss_sums: need 1 <= C <= 8");
-  MISEG_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 4 * C, s));
-  const dim3 grid(grid_for(pixels)), block(256);
-  switch (C) {
-    case 1: hipLaunchKernelGGL(loss_sums_kernel<1>, grid, block, 0, s, gt, pr, sums, pixels); break;
-    case 2: hipLaunchKernelGGL(loss_sums_kernel<2>, grid, block, 0, s, gt, pr, sums, pixels); break;
-    case 3: hipLaunchKernelGGL(loss_sums_kernel<3>, grid, block, 0, s, gt, pr, sums, pixels); break;
-    case 4: hipLaunchKernelGGL(loss_sums_kernel<4>, grid, block, 0, s, gt, pr, sums, pixels); break;
-    case 5: hipLaunchKernelGGL(loss_sums_kernel<5>, grid, block, 0, s, gt, pr, sums, pixels); break;
-    case 6: hipLaunchKernelGGL(loss_sums_kernel<6>, grid, block, 0, s, gt, pr, sums, pixels); break;
-    case 7: hipLaunchKernelGGL(loss_sums_kernel<7>, grid, block, 0, s, gt, pr, sums, pixels); break;
-    default: hipLaunchKernelGGL(loss_sums_kernel<8>, grid, block, 0, s, gt, pr, sums, pixels); break;
-  }
-  MISEG_CHECK_HIP(hipGetLastError());
-  return MISEG_OK;
+  return launch_loss_sums_t<false>(gt, pr, sums, pixels, C, 0.f, 0.f, s);
+}
+
+int launch_loss_sums_focal(const float* gt, const float* pr, double* sums, long long pixels, int C,
+                           float alpha, float gamma, hipStream_t s) {
+  MISEG_CHECK_ARG(alpha > 0.f && gamma >= 0.f, "loss_sums_focal: need alpha > 0, gamma >= 0");
+  return launch_loss_sums_t<true>(gt, pr, sums, pixels, C, alpha, gamma, s);
 }
 
 }  // namespace miseg

@@ -648,7 +648,8 @@ template <int C>
 __global__ void loss_grad_kernel(const float* __restrict__ gt, const float* __restrict__ pr,
                                  const double* __restrict__ sums, bf16_t* __restrict__ dz,
                                  long long pixels, int out_stride, float loss_scale,
-                                 float inv_temperature, int use_cce, int use_dice) {
+                                 float inv_temperature, int use_cce, int use_dice, int use_focal,
+                                 float alpha, float gamma) {
   // Dice: score_c = (2 tp_c + s) / (sum gt_c + sum pr_c + s);  d(1 - mean score)/d pr_{p,c}
   //       = -(2 gt_{p,c} den_c - num_c) / den_c^2 / C
   float dnum[C], dden[C];
@@ -678,9 +679,15 @@ __global__ void loss_grad_kernel(const float* __restrict__ gt, const float* __re
         if (q > 1e-7f && q < 1.f - 1e-7f) gc += -t * cce_w / p[c];
       }
       if (use_dice) gc += dnum[c] - t * dden[c];
+      if (use_focal && t != 0.f && p[c] > 1e-7f && p[c] < 1.f - 1e-7f) {
+        // f = -t alpha (1-p)^gamma log p / (pixels C)
+        const float om = 1.f - p[c];
+        gc += -t * alpha * cce_w * (__powf(om, gamma) / p[c] - gamma * __powf(om, gamma - 1.f) * __logf(p[c]));
+      }
       g[c] = gc * loss_scale;
       dot += g[c] * p[c];
     }
+    // (C == 1, the sigmoid head: dz = g p (1 - p) = p (g - dot) with dot = g p, the same expression)
     if ((out_stride & 7) == 0) {
       // whole line in 16-byte stores: the C gradients, then zeros up to out_stride
       float o[8];
@@ -697,29 +704,40 @@ __global__ void loss_grad_kernel(const float* __restrict__ gt, const float* __re
   }
 }
 
-int launch_loss_grad(const float* gt, const float* pr, const double* sums, void* dz, long long pixels,
-                     int C, int out_stride, float loss_scale, float temperature, int use_cce,
-                     int use_dice, hipStream_t s) {
+int launch_loss_grad_ex(const float* gt, const float* pr, const double* sums, void* dz, long long pixels,
+                        int C, int out_stride, float loss_scale, float temperature, int flags, float alpha,
+                        float gamma, hipStream_t s) {
   MISEG_CHECK_ARG(gt && pr && sums && dz, "loss_grad: null pointer");
-  MISEG_CHECK_ARG(pixels > 0 && C >= 2 && C <= 8 && out_stride >= C && temperature > 0.f,
-                  "loss_grad: need 2 <= C <= 8, out_stride >= C, temperature > 0");
+  MISEG_CHECK_ARG(pixels > 0 && C >= 1 && C <= 8 && out_stride >= C && temperature > 0.f,
+                  "loss_grad: need 1 <= C <= 8, out_stride >= C, temperature > 0");
+  MISEG_CHECK_ARG((flags & 7) != 0 && (flags & ~7) == 0, "loss_grad: flags select cce (1), dice (2), focal (4)");
+  MISEG_CHECK_ARG(!(flags & 4) || (alpha > 0.f && gamma >= 1.f), "loss_grad: focal needs alpha > 0, gamma >= 1");
   const dim3 grid(grid_cap(pixels, 256, 4096)), block(256);
-  const float it = 1.f / temperature;
+  const float it = C == 1 ? 1.f : 1.f / temperature;
   bf16_t* o = (bf16_t*)dz;
+  const int cce = flags & 1, dice = (flags >> 1) & 1, focal = (flags >> 2) & 1;
 #define MISEG_LG(CC)                                                                             \
   case CC:                                                                                       \
     hipLaunchKernelGGL(loss_grad_kernel<CC>, grid, block, 0, s, gt, pr, sums, o, pixels,         \
-                       out_stride, loss_scale, it, use_cce, use_dice);                           \
+                       out_stride, loss_scale, it, cce, dice, focal, alpha, gamma);              \
     break;
   switch (C) {
-    MISEG_LG(2) MISEG_LG(3) MISEG_LG(4) MISEG_LG(5) MISEG_LG(6) MISEG_LG(7)
+    MISEG_LG(1) MISEG_LG(2) MISEG_LG(3) MISEG_LG(4) MISEG_LG(5) MISEG_LG(6) MISEG_LG(7)
     default:
       hipLaunchKernelGGL(loss_grad_kernel<8>, grid, block, 0, s, gt, pr, sums, o, pixels, out_stride,
-                         loss_scale, it, use_cce, use_dice);
+                         loss_scale, it, cce, dice, focal, alpha, gamma);
   }
 #undef MISEG_LG
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
+}
+
+int launch_loss_grad(const float* gt, const float* pr, const double* sums, void* dz, long long pixels,
+                     int C, int out_stride, float loss_scale, float temperature, int use_cce,
+                     int use_dice, hipStream_t s) {
+  MISEG_CHECK_ARG(C >= 2, "loss_grad: need 2 <= C <= 8 (miseg_loss_grad_ex serves the sigmoid head)");
+  return launch_loss_grad_ex(gt, pr, sums, dz, pixels, C, out_stride, loss_scale, temperature,
+                             (use_cce ? 1 : 0) | (use_dice ? 2 : 0), 0.25f, 2.f, s);
 }
 
 // ------------------------------------------------------------------ Adam (Keras form)

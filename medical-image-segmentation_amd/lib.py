@@ -14,6 +14,7 @@ OK = 0
 E_INVALID_ARG, E_UNSUPPORTED_SHAPE, E_HIP, E_NO_DEVICE = -1, -2, -3, -4
 DT_BF16, DT_F32 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SOFTMAX, ACT_SIGMOID = 0, 1, 2, 3
+LOSS_CCE, LOSS_DICE, LOSS_FOCAL = 1, 2, 4
 
 
 class MisegError(RuntimeError):
@@ -92,6 +93,9 @@ SIGNATURES = {
     "miseg_channel_sums": (C.c_int, [_VP, _I64, _I32, _I32, _VP, _VP]),
     "miseg_loss_grad": (C.c_int, [_FP, _FP, _VP, _VP, _I64, _I32, _I32, C.c_float, C.c_float, _I32,
                                   _I32, _VP]),
+    "miseg_loss_grad_ex": (C.c_int, [_FP, _FP, _VP, _VP, _I64, _I32, _I32, C.c_float, C.c_float, _I32,
+                                     C.c_float, C.c_float, _VP]),
+    "miseg_loss_sums_focal": (C.c_int, [_FP, _FP, _VP, _I64, _I32, C.c_float, C.c_float, _VP]),
     "miseg_adam_step": (C.c_int, [_FP, _FP, _FP, _FP, _VP, _I64, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_float, _VP]),
     "miseg_image_minmax": (C.c_int, [_VP, _I32, _I32, _I64, _FP, _VP]),

@@ -20,9 +20,13 @@ class Scalar(float):
         return np.float32(self)
 
 
-def class_sums(gt, pr):
+FOCAL_ALPHA, FOCAL_GAMMA = 0.25, 2.0      # segmentation_models CategoricalFocalLoss defaults
+
+
+def class_sums(gt, pr, focal=False):
     """(4, C) float64: sum(gt*pr), sum(pr), sum(gt), sum(gt*log(clip(pr/sum_c pr)))
-    over all pixels, from one fused GPU pass."""
+    over all pixels, from one fused GPU pass; with `focal` a fifth row,
+    sum(gt * alpha * (1 - q)^gamma * log q), q = clip(pr)."""
     lib = L.load()
     if not torch.cuda.is_available():
         raise L.MisegError("loss/metric sums run on the GPU; no GPU is visible")
@@ -38,10 +42,15 @@ def class_sums(gt, pr):
         raise ValueError("gt and pr shapes differ: %r vs %r" % (tuple(g.shape), tuple(p.shape)))
     c = g.shape[-1]
     pixels = g.numel() // c
-    sums = torch.empty(4 * c, dtype=torch.float64, device=dev)
-    L.check(lib.miseg_loss_sums(g.data_ptr(), p.data_ptr(), sums.data_ptr(), pixels, c,
-                                torch.cuda.current_stream().cuda_stream))
-    return sums.cpu().numpy().reshape(4, c), pixels
+    rows = 5 if focal else 4
+    sums = torch.empty(rows * c, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    if focal:
+        L.check(lib.miseg_loss_sums_focal(g.data_ptr(), p.data_ptr(), sums.data_ptr(), pixels, c,
+                                          FOCAL_ALPHA, FOCAL_GAMMA, st))
+    else:
+        L.check(lib.miseg_loss_sums(g.data_ptr(), p.data_ptr(), sums.data_ptr(), pixels, c, st))
+    return sums.cpu().numpy().reshape(rows, c), pixels
 
 
 def _f1(s):
@@ -58,13 +67,21 @@ def _cce(s, pixels):
     return float(-s[3].sum() / (pixels * s.shape[1]))
 
 
+def _focal(s, pixels):
+    if s.shape[0] < 5:
+        raise ValueError("focal loss needs the five-row sums (class_sums(..., focal=True))")
+    return float(-s[4].sum() / (pixels * s.shape[1]))
+
+
 class _Named:
+    needs_focal = False
+
     def __init__(self, name, fn):
         self.name = self.__name__ = name
         self._fn = fn
 
     def __call__(self, gt, pr):
-        s, pixels = class_sums(gt, pr)
+        s, pixels = class_sums(gt, pr, focal=self.needs_focal)
         return Scalar(self._fn(s, pixels))
 
     def from_sums(self, s, pixels):
@@ -81,14 +98,19 @@ categorical_crossentropy = _Named("categorical_crossentropy", _cce)
 cce_dice_loss = _Named("categorical_crossentropy_plus_dice_loss", lambda s, n: _cce(s, n) + 1.0 - _f1(s))
 
 
-def _focal_unavailable(gt, pr):
-    raise NotImplementedError("focal loss is not implemented on the HIP path yet")
-
-
 class _Focal(_Named):
-    def __call__(self, gt, pr):
-        _focal_unavailable(gt, pr)
+    needs_focal = True
 
 
-categorical_focal_loss = _Focal("focal_loss", None)
-categorical_focal_dice_loss = _Focal("focal_loss_plus_dice_loss", None)
+categorical_focal_loss = _Focal("focal_loss", _focal)
+categorical_focal_dice_loss = _Focal("focal_loss_plus_dice_loss", lambda s, n: _focal(s, n) + 1.0 - _f1(s))
+
+# loss name -> miseg_loss_grad_ex flags
+LOSS_FLAGS = {
+    "categorical_crossentropy_plus_dice_loss": L.LOSS_CCE | L.LOSS_DICE, "cce_dice": L.LOSS_CCE | L.LOSS_DICE,
+    "categorical_crossentropy": L.LOSS_CCE, "cce": L.LOSS_CCE,
+    "dice_loss": L.LOSS_DICE,
+    "focal_loss": L.LOSS_FOCAL, "focal_loss_plus_dice_loss": L.LOSS_FOCAL | L.LOSS_DICE,
+}
+BY_NAME = {o.name: o for o in (dice_loss, categorical_crossentropy, cce_dice_loss, categorical_focal_loss,
+                               categorical_focal_dice_loss)}

@@ -218,15 +218,13 @@ class Model:
     def evaluate(self, dataset, return_dict=True, verbose=0, steps=None):
         """Mean over batches of loss and metrics, as Keras logs them.  `dataset`
         yields (images, one-hot masks)."""
-        loss = self.loss or LS.cce_dice_loss
-        if isinstance(loss, str):
-            loss = {"categorical_crossentropy": LS.categorical_crossentropy}.get(loss, LS.cce_dice_loss)
+        loss = self._loss_object()
         names = ["loss"] + [getattr(m, "name", getattr(m, "__name__", str(m))) for m in self.metrics]
         totals = np.zeros(len(names))
         count = 0
         for images, masks in dataset:
             pr = self(np.asarray(images, np.float32) if not isinstance(images, torch.Tensor) else images)
-            s, pixels = LS.class_sums(masks, pr.tensor)
+            s, pixels = LS.class_sums(masks, pr.tensor, focal=getattr(loss, "needs_focal", False))
             vals = [loss.from_sums(s, pixels)] + [m.from_sums(s, pixels) for m in self.metrics]
             totals += np.asarray(vals)
             count += 1
@@ -238,6 +236,13 @@ class Model:
         return dict(zip(names, map(float, means))) if return_dict else list(map(float, means))
 
     # ---- training ----------------------------------------------------------------------
+    def _loss_object(self):
+        """The compiled loss as an object of losses.py (strings are looked up by name)."""
+        loss = self.loss if self.loss is not None else LS.cce_dice_loss
+        if isinstance(loss, str):
+            loss = LS.BY_NAME.get(loss, LS.cce_dice_loss)
+        return loss
+
     def _loss_name(self):
         loss = self.loss if self.loss is not None else LS.cce_dice_loss
         return loss if isinstance(loss, str) else getattr(loss, "name", getattr(loss, "__name__", str(loss)))
@@ -277,10 +282,8 @@ class Model:
         t = self._trainer(x.shape[0])
         t.lr = float(self.optimizer.learning_rate) if self.optimizer is not None else t.lr
         sums, pixels = t.train_step(x, y)
-        s = sums.cpu().numpy().reshape(4, -1)
-        loss = self.loss if (self.loss is not None and not isinstance(self.loss, str)) else \
-            {"categorical_crossentropy": LS.categorical_crossentropy, "dice_loss": LS.dice_loss}.get(
-                self.loss, LS.cce_dice_loss)
+        s = sums.cpu().numpy().reshape(-1, t.classes)
+        loss = self._loss_object()
         logs = OrderedDict([("loss", loss.from_sums(s, pixels))])
         for m in self.metrics:
             logs[getattr(m, "name", getattr(m, "__name__", str(m)))] = m.from_sums(s, pixels)

@@ -95,15 +95,14 @@ class Trainer:
         self.n = batch
         self.H, self.W, _ = graph.input_shape
         self.classes = graph.classes
-        if self.classes < 2:
-            raise NotImplementedError("training of the single-class (sigmoid) head is not built yet")
         self.lr, self.b1, self.b2, self.eps = learning_rate, beta_1, beta_2, epsilon
         self.step_count = 0
-        self.use_cce = loss in ("cce_dice", "categorical_crossentropy_plus_dice_loss", "cce",
-                                "categorical_crossentropy")
-        self.use_dice = loss in ("cce_dice", "categorical_crossentropy_plus_dice_loss", "dice_loss")
-        if not (self.use_cce or self.use_dice):
+        from . import losses as LS
+        if loss not in LS.LOSS_FLAGS:
             raise NotImplementedError("loss %r is not built on the HIP path" % (loss,))
+        self.loss_flags = LS.LOSS_FLAGS[loss]
+        self.focal = bool(self.loss_flags & L.LOSS_FOCAL)
+        self.focal_alpha, self.focal_gamma = LS.FOCAL_ALPHA, LS.FOCAL_GAMMA
         self.world = world_size
         # encoder_freeze (utils/model.py:179,191,203): the backbone's layers keep their weights and
         # their BatchNormalization layers run on the moving statistics
@@ -662,10 +661,16 @@ class Trainer:
         """gt: fp32 one-hot (n,H,W,classes) device tensor.  Returns dict and keeps the sums."""
         c = self.classes
         self.gt = gt.contiguous()
-        self.loss_sums = torch.empty(4 * c, dtype=torch.float64, device=self.dev)
         pixels = self.n * self.H * self.W
-        L.check(self.lib.miseg_loss_sums(self.gt.data_ptr(), self.probs.data_ptr(), self.loss_sums.data_ptr(),
-                                         pixels, c, self.stream()))
+        if self.focal:
+            self.loss_sums = torch.empty(5 * c, dtype=torch.float64, device=self.dev)
+            L.check(self.lib.miseg_loss_sums_focal(self.gt.data_ptr(), self.probs.data_ptr(),
+                                                   self.loss_sums.data_ptr(), pixels, c, self.focal_alpha,
+                                                   self.focal_gamma, self.stream()))
+        else:
+            self.loss_sums = torch.empty(4 * c, dtype=torch.float64, device=self.dev)
+            L.check(self.lib.miseg_loss_sums(self.gt.data_ptr(), self.probs.data_ptr(),
+                                             self.loss_sums.data_ptr(), pixels, c, self.stream()))
         return self.loss_sums, pixels
 
     # ------------------------------------------------------------------ backward
@@ -704,9 +709,9 @@ class Trainer:
         head = g.layers[g.logits_layer]
         dz = torch.empty((n, self.H, self.W, 32), dtype=torch.bfloat16, device=self.dev)   # the kernel zero-pads
         temp = g.temperature if g.temperature else 1.0
-        L.check(lib.miseg_loss_grad(self.gt.data_ptr(), self.probs.data_ptr(), self.loss_sums.data_ptr(),
-                                    dz.data_ptr(), n * self.H * self.W, c, 32, loss_scale, temp,
-                                    1 if self.use_cce else 0, 1 if self.use_dice else 0, st))
+        L.check(lib.miseg_loss_grad_ex(self.gt.data_ptr(), self.probs.data_ptr(), self.loss_sums.data_ptr(),
+                                       dz.data_ptr(), n * self.H * self.W, c, 32, loss_scale, temp,
+                                       self.loss_flags, self.focal_alpha, self.focal_gamma, st))
         grads[head.name] = Act(dz, c)
         if self.buckets is not None:
             self.buckets.begin()

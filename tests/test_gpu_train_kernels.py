@@ -365,3 +365,57 @@ def test_conv_epilogue_statistics(env, case):
         res.append([t.cpu().numpy() for t in (mean, var, scale, shift, mm, mv)])
     for a, b in zip(*res):
         np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("classes,flags,temp", [(3, 4, 1.0), (3, 6, 1.0), (3, 6, 0.1), (2, 4, 1.0), (1, 2, 1.0),
+                                                (1, 6, 1.0), (1, 3, 1.0)])
+def test_loss_grad_ex_focal_and_sigmoid_match_autograd(env, classes, flags, temp):
+    """miseg_loss_grad_ex / miseg_loss_sums_focal: focal loss (segmentation_models categorical_focal_loss,
+    alpha 0.25, gamma 2; utils/model.py:94-95) and the sigmoid head (classes == 1, utils/model.py:180)
+    against torch autograd of the formulas in oracle/losses.py."""
+    L, lib, dev = env
+    rng = np.random.default_rng(40 + classes + flags)
+    n, h, w = 2, 10, 12
+    alpha, gamma = 0.25, 2.0
+    z = rng.normal(0, 1.5, (n, h, w, classes)).astype(np.float32)
+    if classes == 1:
+        gt = rng.integers(0, 2, (n, h, w, 1)).astype(np.float32)
+    else:
+        gt = np.eye(classes, dtype=np.float32)[rng.integers(0, classes, (n, h, w))]
+    zt = torch.from_numpy(z).requires_grad_(True)
+    pr = torch.sigmoid(zt) if classes == 1 else torch.softmax(zt / temp, dim=-1)
+    g = torch.from_numpy(gt)
+    loss = 0.0
+    if flags & 1:
+        q = torch.clamp(pr / pr.sum(-1, keepdim=True), 1e-7, 1 - 1e-7)
+        loss = loss + torch.mean(-g * torch.log(q))
+    if flags & 2:
+        tp = (g * pr).sum((0, 1, 2))
+        loss = loss + 1 - ((2 * tp + 1e-5) / (g.sum((0, 1, 2)) + pr.sum((0, 1, 2)) + 1e-5)).mean()
+    focal_val = None
+    if flags & 4:
+        q = torch.clamp(pr, 1e-7, 1 - 1e-7)
+        fl = torch.mean(-g * alpha * (1 - q) ** gamma * torch.log(q))
+        focal_val = float(fl.detach())
+        loss = loss + fl
+    (0.5 * loss).backward()
+    want = zt.grad.numpy()
+    prd, gtd = df32(pr.detach().numpy(), dev), df32(gt, dev)
+    sums = torch.zeros(5 * classes, dtype=torch.float64, device=dev)
+    L.check(lib.miseg_loss_sums_focal(gtd.data_ptr(), prd.data_ptr(), sums.data_ptr(), n * h * w, classes,
+                                      alpha, gamma, None))
+    torch.cuda.synchronize()
+    s = sums.cpu().numpy().reshape(5, classes)
+    if focal_val is not None:
+        assert abs(-s[4].sum() / gt.size - focal_val) <= 1e-5 * max(1.0, abs(focal_val))
+    ref4 = torch.zeros(4 * classes, dtype=torch.float64, device=dev)
+    L.check(lib.miseg_loss_sums(gtd.data_ptr(), prd.data_ptr(), ref4.data_ptr(), n * h * w, classes, None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(s[:4].ravel(), ref4.cpu().numpy(), rtol=1e-12)
+    dz = torch.full((n, h, w, 8), 7.0, dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_loss_grad_ex(gtd.data_ptr(), prd.data_ptr(), sums.data_ptr(), dz.data_ptr(), n * h * w,
+                                   classes, 8, 0.5, temp, flags, alpha, gamma, None))
+    torch.cuda.synchronize()
+    got = dz.float().cpu().numpy()
+    np.testing.assert_allclose(got[..., :classes], want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
+    assert np.all(got[..., classes:] == 0)

@@ -116,3 +116,37 @@ def test_training_reduces_loss_like_the_oracle(pkg):
     assert abs(mine[0] - ref[0]) <= 1e-2 * ref[0], (mine[0], ref[0])
     assert mine[-1] < 0.75 * mine[0], mine
     assert abs(mine[-1] - ref[-1]) <= 0.15 * ref[-1], (mine[-1], ref[-1])
+
+
+@pytest.mark.parametrize("classes,loss", [(3, "focal_loss_plus_dice_loss"), (3, "focal_loss"), (1, "dice_loss")])
+def test_focal_loss_and_sigmoid_head_train(pkg, classes, loss):
+    """The remaining selectable losses (model_train.py:172-177) and the single-class sigmoid head
+    (utils/model.py:180) go through a few optimisation steps: the reported loss equals the numpy
+    restatement (oracle/losses.py) on the probabilities the step produced, and it decreases."""
+    import torch
+    from miseg_amd import netspec, trainer, losses as LS
+    from oracle import nets, losses as OL
+    act = "sigmoid" if classes == 1 else "softmax"
+    w = nets.init_weights(nets.build_spec("resnet18", "U-Net", classes), 0, True)
+    g = netspec.build_graph("resnet18", "U-Net", (64, 96, 3), classes, act, None)
+    rng = np.random.default_rng(3)
+    x = rng.random((2, 64, 96, 3), dtype=np.float32)
+    if classes == 1:
+        y = (rng.random((2, 64, 96, 1)) < 0.4).astype(np.float32)
+    else:
+        y = np.eye(classes, dtype=np.float32)[np.repeat(np.repeat(rng.integers(0, classes, (2, 8, 12)), 8, 1), 8, 2)]
+    tr = trainer.Trainer(g, w, 2, learning_rate=1e-3, loss=loss)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    vals = []
+    obj = LS.BY_NAME[loss]
+    for it in range(12):
+        sums, pixels = tr.train_step(xd, yd)
+        s = sums.cpu().numpy().reshape(-1, classes)
+        vals.append(obj.from_sums(s, pixels))
+        if it == 0:
+            pr = tr.probs.cpu().numpy()
+            want = {"focal_loss_plus_dice_loss": OL.categorical_focal_dice_loss, "focal_loss": OL.categorical_focal_loss,
+                    "dice_loss": OL.dice_loss}[loss](y, pr)
+            assert abs(vals[0] - want) <= 1e-4 * max(1.0, abs(want)), (vals[0], want)
+    assert np.isfinite(vals).all()
+    assert vals[-1] < vals[0], vals
