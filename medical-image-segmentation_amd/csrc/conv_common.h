@@ -392,6 +392,161 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Epilogue straight from the accumulators, without LDS, for one 32-cout group per wave and bf16
+// outputs.  A 32x32 accumulator tile leaves lane (pixel j, half h) with couts 8g + 4h + r
+// (g, r = 0..3); four v_permlane32_swap per 8 values trade the g = 1 (3) quads of the lower
+// half-wave for the g = 0 (2) quads of the upper one, after which lane (j, h) owns couts
+// [8h, 8h + 8) and [16 + 8h, 16 + 8h + 8) of its pixel: two 16-byte stores, and a store
+// instruction writes 32 contiguous bytes per pixel.  Nothing here waits on anything but the
+// residual loads, which are requested four pixel rows at a time.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool direct_epilogue_ok(const ConvParams& p) {
+  return p.vec_ok && p.out && p.out_dtype == MISEG_DT_BF16 && (p.Cout & 7) == 0 && !p.stats &&
+         (!p.residual || p.res_dtype == MISEG_DT_BF16) && p.act != MISEG_ACT_SOFTMAX &&
+         p.act != MISEG_ACT_SIGMOID;
+}
+
+// coefficients of couts [c, c + 8) (or `fill` when the vector is absent / the group is past Cout)
+__device__ __forceinline__ void load_coef8(const float* src, int c, int Cout, float* d, float fill) {
+  if (src && c + 8 <= Cout) {
+    const float4 a = *reinterpret_cast<const float4*>(src + c);
+    const float4 b = *reinterpret_cast<const float4*>(src + c + 4);
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+    d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = fill;
+  }
+}
+
+// What a lane needs to finish accumulator tiles of one 32-cout group: its two cout octets and the
+// coefficients of those 16 couts.
+struct DirectLane {
+  int c2[2];          // first cout of each octet
+  bool okc[2];        // octet inside Cout
+  float sc[16], sh[16];
+  bool relu;
+};
+// coefficients of the second output (BatchNorm + ReLU of the first) for the same couts
+struct DirectOut2 {
+  float s2[16], t2[16];
+};
+__device__ __forceinline__ void direct_lane_init(const ConvParams& p, int cbase, int lane, DirectLane& d) {
+  const int lhalf = lane >> 5;
+  d.c2[0] = cbase + 8 * lhalf;
+  d.c2[1] = cbase + 16 + 8 * lhalf;
+  d.relu = p.act == MISEG_ACT_RELU;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    d.okc[q] = d.c2[q] + 8 <= p.Cout;
+    load_coef8(p.scale, d.c2[q], p.Cout, d.sc + 8 * q, 1.f);
+    load_coef8(p.shift, d.c2[q], p.Cout, d.sh + 8 * q, 0.f);
+  }
+}
+__device__ __forceinline__ void direct_out2_init(const ConvParams& p, const DirectLane& d, DirectOut2& o) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    load_coef8(p.scale2, d.c2[q], p.Cout, o.s2 + 8 * q, 1.f);
+    load_coef8(p.shift2, d.c2[q], p.Cout, o.t2 + 8 * q, 0.f);
+  }
+}
+
+// One 32x32 accumulator tile -> memory.  EVERY lane of the wave must call this (the swaps are
+// cross-lane); `okp` says whether this lane's pixel exists.  o_off / o2_off: element offsets of
+// the pixel in out / out2; res: the residual's two octets (used when has_res); d2: null when
+// there is no second output.
+__device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLane& d, const f32x16& a,
+                                            bool okp, long long o_off, long long o2_off, bool has_res,
+                                            const uint4 (&res)[2], const DirectOut2* d2) {
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[8 * q + r]),
+                                                       __float_as_uint(a[8 * q + 4 + r]), false, false);
+      v[8 * q + r] = __uint_as_float(sw[0]);
+      v[8 * q + 4 + r] = __uint_as_float(sw[1]);
+    }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = v[j] * d.sc[j] + d.sh[j];
+  if (has_res) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint4 r = res[q];
+      v[8 * q + 0] += bf16lo_to_f32(r.x); v[8 * q + 1] += bf16hi_to_f32(r.x);
+      v[8 * q + 2] += bf16lo_to_f32(r.y); v[8 * q + 3] += bf16hi_to_f32(r.y);
+      v[8 * q + 4] += bf16lo_to_f32(r.z); v[8 * q + 5] += bf16hi_to_f32(r.z);
+      v[8 * q + 6] += bf16lo_to_f32(r.w); v[8 * q + 7] += bf16hi_to_f32(r.w);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (!(okp && d.okc[q])) continue;
+    const float* w = v + 8 * q;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = d.relu ? fmaxf(w[j], 0.f) : w[j];
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o_off + d.c2[q]) =
+        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                   pack_bf16x2(o[6], o[7]));
+    if (d2) {
+      const float* s = d2->s2 + 8 * q;
+      const float* t = d2->t2 + 8 * q;
+      *reinterpret_cast<uint4*>(p.out2 + o2_off + d.c2[q]) = make_uint4(
+          pack_bf16x2(fmaxf(w[0] * s[0] + t[0], 0.f), fmaxf(w[1] * s[1] + t[1], 0.f)),
+          pack_bf16x2(fmaxf(w[2] * s[2] + t[2], 0.f), fmaxf(w[3] * s[3] + t[3], 0.f)),
+          pack_bf16x2(fmaxf(w[4] * s[4] + t[4], 0.f), fmaxf(w[5] * s[5] + t[5], 0.f)),
+          pack_bf16x2(fmaxf(w[6] * s[6] + t[6], 0.f), fmaxf(w[7] * s[7] + t[7], 0.f)));
+    }
+  }
+}
+
+// All MT pixel rows of a wave (pixel index = wm * MT * 32 + b * 32 + lane % 32 through `decode`).
+template <int MT, class Decode>
+__device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const TileCoord& tc,
+                                                     const Decode& decode, f32x16 (&acc)[1][MT],
+                                                     int wm, int lane, const DirectLane& d) {
+  const int lrow = lane & 31;
+  const bool has_res = p.residual != nullptr;
+  DirectOut2 o2;
+  if (p.out2) direct_out2_init(p, d, o2);
+  constexpr int RG = MT < 4 ? MT : 4;   // pixel rows per residual request group
+  static_assert(MT % RG == 0, "row groups");
+  static_for<MT / RG>([&](auto gc) __attribute__((always_inline)) {
+    constexpr int b0 = decltype(gc)::value * RG;
+    bool okp[RG];
+    long long o_off[RG], o2_off[RG];
+    uint4 res[RG][2];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+      int n, oy, ox, rem;
+      okp[i] = decode(wm * (MT * 32) + (b0 + i) * 32 + lrow, n, oy, ox, rem);
+      if (!okp[i]) n = oy = ox = 0;
+      if (p.transposed) {
+        oy = 2 * oy + tc.ph_a;
+        ox = 2 * ox + tc.ph_b;
+      }
+      o_off[i] = n * p.out_img_stride + (long long)oy * p.out_row_stride + (long long)ox * p.out_pix_stride;
+      o2_off[i] = n * p.out2_img_stride + (long long)oy * p.out2_row_stride + (long long)ox * p.out2_pix_stride;
+      if (has_res) {
+        const long long r_off = n * p.res_img_stride + (long long)oy * p.res_row_stride +
+                                (long long)ox * p.res_pix_stride;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          res[i][q] = okp[i] && d.okc[q]
+                          ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.residual) + r_off + d.c2[q])
+                          : make_uint4(0, 0, 0, 0);
+      }
+    }
+    static_for<RG>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      direct_tile(p, d, acc[0][b0 + i], okp[i], o_off[i], o2_off[i], has_res, res[i], p.out2 ? &o2 : nullptr);
+    });
+  });
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NT][MT]) {
 #pragma unroll
@@ -439,6 +594,13 @@ __device__ __forceinline__ void lgkm_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x
 template <int CNT>
 __device__ __forceinline__ void lgkm_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e) {
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(CNT));
+}
+
+// Waits for every outstanding LDS operation; the 12 fragments of a K step are threaded through.
+__device__ __forceinline__ void lgkm_wait12(bf16x8 (&x)[12]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]),
+                 "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
 }
 
 }  // namespace miseg

@@ -230,11 +230,257 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
 #undef MISEG_DS_READ
 #undef MISEG_LGKM_WAIT
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+  if (direct_epilogue_ok(p)) {
+    // straight from the accumulators: no LDS, no waits between the rows' stores
+    DirectLane dl;
+    direct_lane_init(p, tc.cout0 + cgrp * 32, lane, dl);
+    conv_epilogue_direct<MT>(p, tc, dec, acc, wm, lane, dl);
+    return;
+  }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
   conv_epilogue<WARPS_N, MT, 1>(p, tc, dec, acc, lds, wm, cgrp, lane, wave);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Conv2DTranspose(4, 2, 'same') with 64 input channels and <= 32 output channels (the last
+// transpose of the U-Net decoder, 64 -> 32 at full resolution): 1 MAC per 3 bytes of traffic, so
+// the layer is bound by HBM and, in the kernel above, by how it stores: a wave that owns ONE
+// output phase writes 64-byte pieces 128 bytes apart and reaches 2/3 of the store rate of a
+// wave whose consecutive store instructions complete whole 128-byte lines.
+//
+// One persistent block per CU.  Wave w owns the row phase w / 2 of pixel rows 4 (w % 2) ..
+// + 3 of the block's 8 x 32 input patch, and BOTH column phases: eight 32 x 32 accumulator
+// tiles (column phase x row).  The two column phases read the same pixel fragments (halo
+// columns x, x + 1 for the even phase, x + 1, x + 2 for the odd one), so a K step needs 12
+// pixel fragments for 16 MFMAs.  The wave's weights (2 phases x 4 taps x 64 k x 32 couts) stay
+// in 128 registers for the life of the block.  LDS holds only the halo, double-buffered: the
+// next patch's halo is requested before the arithmetic of the current one.  The epilogue goes
+// straight from the accumulators to memory: four consecutive 16-byte-per-lane stores complete
+// the 128 bytes (2 phases x 32 couts) of every pixel of a row.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int CT_LDS = 2 * PW_HALO_BYTES;  // 96 KB
+}  // namespace
+
+#ifdef MISEG_CT_PROFILE
+// phase timers of block b (100 MHz ticks): [0] top barrier wait, [1] halo issue, [2] arithmetic,
+// [3] vmcnt wait, [4] epilogue, [6] patches
+__device__ unsigned long long g_ct_prof[1024][8];
+#define CT_TICK(i) do { const unsigned long long t__ = wall_clock64(); ct_t[i] += t__ - ct_last; ct_last = t__; } while (0)
+#else
+#define CT_TICK(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(256, 1) void convT_c64_kernel(const ConvParams p) {
+#ifdef MISEG_CT_PROFILE
+  unsigned long long ct_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct_last = wall_clock64();
+#endif
+  constexpr int TH = PW_TH, TW = PW_TW, HWD = PW_HWD, PITCH = PW_PITCH, NHW = PW_NHI / 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CT_LDS + 256];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph_a = wave >> 1, half = wave & 1;
+  const int per_img = p.tiles_y * p.tiles_x;
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const unsigned lds_a = (unsigned)(unsigned long long)(lds_byte*)lds;
+  const unsigned char* zero_src = g_zero_line;
+
+  // ---- weights of phases (ph_a, 0) and (ph_a, 1): fragment [pb][tap][kk] = cout lrow,
+  //      k = kk * 16 + lhalf * 8 .. + 7 of tap `tap` ----
+  bf16x8 wreg[2][4][4];
+  static_for<32>([&](auto ic) __attribute__((always_inline)) {
+    constexpr int pb = decltype(ic)::value >> 4, tap = (decltype(ic)::value >> 2) & 3, kk = decltype(ic)::value & 3;
+    // rows past Cout repeat row 0: their results are never stored
+    const bf16_t* wsrc = p.weight + (long long)(ph_a * 2 + pb) * p.Cout * 4 * 64 + (lrow < p.Cout ? lrow : 0) * 4 * 64 + lhalf * 8;
+    wreg[pb][tap][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wsrc + tap * 64 + kk * 16));
+  });
+  // ---- halo requests: lane constants (position inside the halo) + per-patch origin ----
+  // (one word per request: halo row | column << 8 | 16-byte slot << 16, or -1 for padding)
+  int hl[NHW];
+#pragma unroll
+  for (int j = 0; j < NHW; ++j) {
+    const int o = (4 * j + wave) * 1024 + lane * 16;
+    const int hr = o / PITCH;
+    const int sl = (o - hr * PITCH) >> 4;
+    const int hy = hr / HWD;
+    const int hx = hr - hy * HWD;
+    hl[j] = hr < PW_HROWS && sl < 8 ? (hy | (hx << 8) | (sl << 16)) : -1;
+  }
+  // Patch order: blocks b, b + 8, .. share an XCD and its L2; each XCD walks its own contiguous
+  // eighth of the patches, its CUs side by side, so that neighbouring halos meet in one L2.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nslot = (gridDim.x + 7 - xcd) >> 3;          // blocks on this XCD
+  const int per_xcd = (p.mtiles + 7) >> 3;
+  const int t_begin = xcd * per_xcd;
+  const int t_end = t_begin + per_xcd < p.mtiles ? t_begin + per_xcd : p.mtiles;
+  auto patch_origin = [&](int tile, int& n, int& y0, int& x0) {
+    n = tile / per_img;
+    const int trem = tile - n * per_img;
+    const int tyi = trem / p.tiles_x;
+    y0 = tyi * TH;
+    x0 = (trem - tyi * p.tiles_x) * TW;
+  };
+  auto issue_halo = [&](int tile, int buf) {
+    int n, y0, x0;
+    patch_origin(tile, n, y0, x0);
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(p.in + n * p.in_img_stride) +
+                                ((long long)(y0 - 1) * p.in_row_stride + (long long)(x0 - 1) * p.in_pix_stride) * 2;
+#pragma unroll
+    for (int j = 0; j < NHW; ++j) {
+      int h = hl[j];
+      asm volatile("" : "+v"(h));   // keep the unpacking inside the loop: 12 words live, not 60
+      const int hy = h & 255, hx = (h >> 8) & 255, sl = h >> 16;
+      const bool ok = h >= 0 && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+      const unsigned char* src = ok ? base + (hy * p.in_row_stride + hx * p.in_pix_stride + sl * 8) * 2 : zero_src;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(lds + buf * PW_HALO_BYTES + (4 * j + wave) * 1024), 16, 0, 0);
+    }
+  };
+
+  // pixel fragment (row b, tap row dy, halo column c, sub-step kk) =
+  //   xl + ((b + dy) * HWD + c) * PITCH + kk * 32
+  const unsigned xl0 = lds_a + ((half * 4 + ph_a) * HWD + lrow) * PITCH + lhalf * 16;
+
+  // epilogue coefficients live in LDS between patches (registers are full): scale[32] | shift[32]
+  const bool direct = direct_epilogue_ok(p) && !p.residual && !p.out2;
+  float* coef = reinterpret_cast<float*>(lds + CT_LDS);
+  if (tid < 64) {
+    const int c = tid & 31;
+    const float* src = tid < 32 ? p.scale : p.shift;
+    coef[tid] = (src && c < p.Cout) ? src[c] : (tid < 32 ? 1.f : 0.f);
+  }
+  DirectLane dl;
+  dl.c2[0] = 8 * lhalf;
+  dl.c2[1] = 16 + 8 * lhalf;
+  dl.okc[0] = dl.c2[0] + 8 <= p.Cout;
+  dl.okc[1] = dl.c2[1] + 8 <= p.Cout;
+  dl.relu = p.act == MISEG_ACT_RELU;
+  const unsigned coef_a = lds_a + CT_LDS + lhalf * 32;
+  __syncthreads();
+
+  int tile = t_begin + slot;
+  if (tile < t_end) issue_halo(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int cur = 0;
+  for (; tile < t_end; tile += nslot, cur ^= 1) {
+    // every wave has waited for its share of this patch's halo and is done with the other buffer
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    CT_TICK(0);
+#ifdef MISEG_CT_PROFILE
+    if (!(p.collapse_value & 2))
+#endif
+    if (tile + nslot < t_end) issue_halo(tile + nslot, cur ^ 1);
+    const unsigned xl = xl0 + cur * PW_HALO_BYTES;
+    CT_TICK(1);
+
+    f32x16 acc[2][1][4];   // [column phase][.][row]
+    zero_acc<4, 1>(acc[0]);
+    zero_acc<4, 1>(acc[1]);
+    bf16x8 xf[2][12];
+    // K step s = (dy, kk): 12 fragment reads (4 rows x 3 columns) one step ahead of 16 MFMAs
+    auto read_step = [&](auto sc_, bf16x8 (&x)[12]) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int dy = s >> 2, kk = s & 3;
+      static_for<12>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        ds_read_b128_at<((i / 3 + dy) * HWD + i % 3) * PITCH + kk * 32>(x[i], xl);
+      });
+    };
+    auto wait_step = [&](bf16x8 (&x)[12]) __attribute__((always_inline)) { lgkm_wait12(x); };
+    read_step(std::integral_constant<int, 0>{}, xf[0]);
+    wait_step(xf[0]);
+    static_for<8>([&](auto sc_) __attribute__((always_inline)) {
+      constexpr int s = decltype(sc_)::value;
+      constexpr int dy = s >> 2, kk = s & 3;
+      if constexpr (s < 7) read_step(std::integral_constant<int, s + 1>{}, xf[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<16>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int dx = m >> 3, b = (m >> 1) & 3, pb = m & 1;
+        acc[pb][0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[pb][dy * 2 + dx][kk],
+                                                                xf[s & 1][b * 3 + pb + dx], acc[pb][0][b], 0, 0, 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (s < 7) wait_step(xf[(s + 1) & 1]);
+    });
+    CT_TICK(2);
+    // the next patch's halo has landed: it had the whole arithmetic phase
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    CT_TICK(3);
+    int n, y0, x0;
+    patch_origin(tile, n, y0, x0);
+#ifdef MISEG_CT_PROFILE
+    if (p.collapse_value & 1) {
+      if (acc[0][0][0][0] == 123.456f && acc[1][0][3][5] == 3.f) reinterpret_cast<float*>(p.out)[0] = 1.f;
+    } else
+#endif
+    if (direct) {
+      {
+        // scale | shift of couts [8h, 8h + 8) and [16 + 8h, 16 + 8h + 8)
+        bf16x8 c[8];
+        ds_read_b128_at<0>(c[0], coef_a);
+        ds_read_b128_at<16>(c[1], coef_a);
+        ds_read_b128_at<64>(c[2], coef_a);
+        ds_read_b128_at<80>(c[3], coef_a);
+        ds_read_b128_at<128>(c[4], coef_a);
+        ds_read_b128_at<144>(c[5], coef_a);
+        ds_read_b128_at<192>(c[6], coef_a);
+        ds_read_b128_at<208>(c[7], coef_a);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float4 a = __builtin_bit_cast(float4, c[i]);
+          const float4 b = __builtin_bit_cast(float4, c[4 + i]);
+          dl.sc[4 * i] = a.x; dl.sc[4 * i + 1] = a.y; dl.sc[4 * i + 2] = a.z; dl.sc[4 * i + 3] = a.w;
+          dl.sh[4 * i] = b.x; dl.sh[4 * i + 1] = b.y; dl.sh[4 * i + 2] = b.z; dl.sh[4 * i + 3] = b.w;
+        }
+      }
+      const int ix = x0 + lrow;
+      const uint4 nores[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+      static_for<8>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int b = decltype(mc)::value >> 1, pb = decltype(mc)::value & 1;
+        const int iy = y0 + half * 4 + b;
+        const bool okp = iy < p.Ho && ix < p.Wo;
+        const long long o_off = n * p.out_img_stride + (long long)(2 * iy + ph_a) * p.out_row_stride +
+                                (long long)(2 * ix + pb) * p.out_pix_stride;
+        direct_tile(p, dl, acc[pb][0][b], okp, okp ? o_off : 0, 0, false, nores, nullptr);
+      });
+    } else {
+      // generic epilogue through LDS scratch that aliases the buffer just computed from
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+      static_for<2>([&](auto pc) __attribute__((always_inline)) {
+        constexpr int pb = decltype(pc)::value;
+        TileCoord tc;
+        tc.m0 = 0; tc.cout0 = 0; tc.ph_a = ph_a; tc.ph_b = pb; tc.pad_y = tc.pad_x = 0;
+        tc.wbase = p.weight;
+        conv_epilogue<4, 4, 1>(p, tc, dec, acc[pb], lds + cur * PW_HALO_BYTES, half, 0, lane, wave);
+      });
+    }
+    CT_TICK(4);
+#ifdef MISEG_CT_PROFILE
+    ct_t[6] += 1;
+#endif
+  }
+#ifdef MISEG_CT_PROFILE
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) g_ct_prof[blockIdx.x * 4 + wave][i] = ct_t[i];
+#endif
+}
+
 hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s) {
+  if (p.transposed && p.Cin == 64 && p.Cout <= 32 && !p.stats) {
+    // persistent, one block per CU
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int blocks = p.mtiles < cus ? p.mtiles : cus;
+    hipLaunchKernelGGL(convT_c64_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+  }
   if (p.transposed)
     hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, true>), grid, dim3(256), 0, s, p);
   else

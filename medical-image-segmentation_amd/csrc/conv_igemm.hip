@@ -802,6 +802,8 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
                                 "", "8, 32, 4, 1, 2, 1, 1"};
   if (kc.kind == K_C32)
     snprintf(buf, len, "conv3x3_c32_kernel<8, 32>");
+  else if (kc.kind == K_HALO_PW && d->transposed && d->Cin == 64 && d->Cout <= 32 && !d->stats)
+    snprintf(buf, len, "convT_c64_kernel");
   else if (kc.kind == K_HALO_PW)
     snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, %s>", d->transposed ? "true" : "false");
   else if (kc.kind == K_HALO)

@@ -212,6 +212,43 @@ def test_conv_transpose_4x4s2(env, shape, hint):
     np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("shape", [(3, 100, 300, 64, 32), (2, 77, 250, 64, 24), (1, 8, 32, 64, 32)])
+def test_conv_transpose_c64_persistent(env, shape):
+    """64 -> (<= 32) channels: one block per CU walks several patches with the next halo in
+    flight; more patches than CUs, ragged borders and a ragged channel count."""
+    from oracle import ops_torch
+    L, lib, dev = env
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(23)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    k = bf16_round(rng.normal(0, 0.1, (4, 4, cout, cin)))
+    want = ops_torch.to_numpy(ops_torch.conv2d_transpose_4x4s2(ops_torch.asarray(x), k))
+    ph = np.zeros((2, 2, cout, 2, 2, cin), np.float32)
+    for a in range(2):
+        for b in range(2):
+            for dy in range(2):
+                for dx in range(2):
+                    ph[a, b, :, dy, dx, :] = k[3 - a - 2 * dy, 3 - b - 2 * dx]
+    xin, wt = dev_bf16(x, dev), dev_bf16(ph, dev)
+    for dt, tdt in ((L.DT_F32, torch.float32), (L.DT_BF16, torch.bfloat16)):
+        out = torch.zeros((n, 2 * h, 2 * w, cout), dtype=tdt, device=dev)
+        d = L.ConvDesc()
+        d.inp, d.weight, d.out = xin.data_ptr(), wt.data_ptr(), out.data_ptr()
+        d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, h, w, cout
+        d.KH = d.KW = 2
+        d.stride_y = d.stride_x = 1
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin, cin * w, cin * w * h
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * 2 * w, cout * 4 * w * h
+        d.out_dtype, d.transposed, d.temperature = dt, 1, 1.0
+        L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+        torch.cuda.synchronize()
+        got = out.float().cpu().numpy()
+        if dt == L.DT_F32:
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-4)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("classes,act", [(3, 2), (4, 2), (1, 3), (2, 2)])
 def test_conv_head_softmax_collapse(env, classes, act):
     """3x3 head + bias + softmax/sigmoid + strict-argmax collapse in the epilogue."""
