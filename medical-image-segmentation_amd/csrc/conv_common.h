@@ -506,7 +506,7 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
 // All MT pixel rows of a wave (pixel index = wm * MT * 32 + b * 32 + lane % 32 through `decode`).
 template <int MT, class Decode>
 __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const TileCoord& tc,
-                                                     const Decode& decode, f32x16 (&acc)[1][MT],
+                                                     const Decode& decode, f32x16 (&acc)[MT],
                                                      int wm, int lane, const DirectLane& d) {
   const int lrow = lane & 31;
   const bool has_res = p.residual != nullptr;
@@ -542,8 +542,23 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const 
     }
     static_for<RG>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      direct_tile(p, d, acc[0][b0 + i], okp[i], o_off[i], o2_off[i], has_res, res[i], p.out2 ? &o2 : nullptr);
+      direct_tile(p, d, acc[b0 + i], okp[i], o_off[i], o2_off[i], has_res, res[i], p.out2 ? &o2 : nullptr);
     });
+  });
+}
+
+// A wave tile of NT cout groups: group a covers couts [cbase + 32 a, cbase + 32 a + 32).
+template <int MT, int NT, class Decode>
+__device__ __forceinline__ void conv_epilogue_direct_groups(const ConvParams& p, const TileCoord& tc,
+                                                            const Decode& decode, f32x16 (&acc)[NT][MT],
+                                                            int wm, int cbase, int lane) {
+  static_for<NT>([&](auto ac) __attribute__((always_inline)) {
+    constexpr int a = decltype(ac)::value;
+    if (cbase + a * 32 < p.Cout) {
+      DirectLane dl;
+      direct_lane_init(p, cbase + a * 32, lane, dl);
+      conv_epilogue_direct<MT>(p, tc, decode, acc[a], wm, lane, dl);
+    }
   });
 }
 

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
     // straight from the accumulators: no LDS, no waits between the rows' stores
     DirectLane dl;
     direct_lane_init(p, tc.cout0 + cgrp * 32, lane, dl);
-    conv_epilogue_direct<MT>(p, tc, dec, acc, wm, lane, dl);
+    conv_epilogue_direct<MT>(p, tc, dec, acc[0], wm, lane, dl);
     return;
   }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read

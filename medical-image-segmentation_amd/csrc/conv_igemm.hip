@@ -172,6 +172,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
   }
   const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
+  if (direct_epilogue_ok(p)) {
+    // straight from the accumulators: no LDS, no waits between the rows' stores
+    conv_epilogue_direct_groups<MT, NT>(p, tc, dec, acc, wm, tc.cout0 + wn * (NT * 32), lane);
+    return;
+  }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
   conv_epilogue<WARPS_N, MT, NT>(p, tc, dec, acc, lds, wm, wn, lane);
 }
@@ -314,6 +319,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     compute(ks & 1);
   }
   const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
+  if (direct_epilogue_ok(p)) {
+    // straight from the accumulators: no LDS, no waits between the rows' stores
+    conv_epilogue_direct_groups<MT, NT>(p, tc, dec, acc, wm, tc.cout0 + wn * (NT * 32), lane);
+    return;
+  }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
   conv_epilogue<WARPS_N, MT, NT>(p, tc, dec, acc, lds, wm, wn, lane);
 }
@@ -502,6 +512,11 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
     }
   }
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+  if (direct_epilogue_ok(p)) {
+    // straight from the accumulators: no LDS, no waits between the rows' stores
+    conv_epilogue_direct_groups<MT, NT>(p, tc, dec, acc, wm, tc.cout0 + wn * (NT * 32), lane);
+    return;
+  }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
   conv_epilogue<WARPS_N, MT, NT>(p, tc, dec, acc, lds, wm, wn, lane);
 }
@@ -609,6 +624,10 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const ConvParams p) {
     }
   }
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+  if (direct_epilogue_ok(p)) {
+    conv_epilogue_direct_groups<MT, 1>(p, tc, dec, acc, wave, tc.cout0, lane);
+    return;
+  }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
   conv_epilogue<1, MT, 1>(p, tc, dec, acc, lds, wave, 0, lane);
 }
