@@ -402,7 +402,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
 // residual loads, which are requested four pixel rows at a time.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool direct_epilogue_ok(const ConvParams& p) {
-  return p.vec_ok && p.out && p.out_dtype == MISEG_DT_BF16 && (p.Cout & 7) == 0 && !p.stats &&
+  return p.vec_ok && p.out && p.out_dtype == MISEG_DT_BF16 && (p.Cout & 7) == 0 &&
          (!p.residual || p.res_dtype == MISEG_DT_BF16) && p.act != MISEG_ACT_SOFTMAX &&
          p.act != MISEG_ACT_SIGMOID;
 }
@@ -455,10 +455,11 @@ __device__ __forceinline__ void direct_out2_init(const ConvParams& p, const Dire
 // One 32x32 accumulator tile -> memory.  EVERY lane of the wave must call this (the swaps are
 // cross-lane); `okp` says whether this lane's pixel exists.  o_off / o2_off: element offsets of
 // the pixel in out / out2; res: the residual's two octets (used when has_res); d2: null when
-// there is no second output.
+// there is no second output; st: null, or this lane's running sum [0, 16) and sum of squares
+// [16, 32) of the stored (bf16-rounded) values of its 16 couts.
 __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLane& d, const f32x16& a,
                                             bool okp, long long o_off, long long o2_off, bool has_res,
-                                            const uint4 (&res)[2], const DirectOut2* d2) {
+                                            const uint4 (&res)[2], const DirectOut2* d2, float* st, bool do_stats) {
   float v[16];
 #pragma unroll
   for (int q = 0; q < 2; ++q)
@@ -488,9 +489,18 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = d.relu ? fmaxf(w[j], 0.f) : w[j];
-    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o_off + d.c2[q]) =
-        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
-                   pack_bf16x2(o[6], o[7]));
+    const uint4 pk = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                                pack_bf16x2(o[6], o[7]));
+    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o_off + d.c2[q]) = pk;
+    if (do_stats) {
+      const float r[8] = {bf16lo_to_f32(pk.x), bf16hi_to_f32(pk.x), bf16lo_to_f32(pk.y), bf16hi_to_f32(pk.y),
+                          bf16lo_to_f32(pk.z), bf16hi_to_f32(pk.z), bf16lo_to_f32(pk.w), bf16hi_to_f32(pk.w)};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        st[8 * q + j] += r[j];
+        st[16 + 8 * q + j] += r[j] * r[j];
+      }
+    }
     if (d2) {
       const float* s = d2->s2 + 8 * q;
       const float* t = d2->t2 + 8 * q;
@@ -507,12 +517,13 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
 template <int MT, class Decode>
 __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const TileCoord& tc,
                                                      const Decode& decode, f32x16 (&acc)[MT],
-                                                     int wm, int lane, const DirectLane& d) {
+                                                     int wm, int lane, const DirectLane& d,
+                                                     float (&st)[32], bool do_stats) {
   const int lrow = lane & 31;
   const bool has_res = p.residual != nullptr;
   DirectOut2 o2;
   if (p.out2) direct_out2_init(p, d, o2);
-  constexpr int RG = MT < 4 ? MT : 4;   // pixel rows per residual request group
+  constexpr int RG = MT < 2 ? MT : 2;   // pixel rows per residual request group
   static_assert(MT % RG == 0, "row groups");
   static_for<MT / RG>([&](auto gc) __attribute__((always_inline)) {
     constexpr int b0 = decltype(gc)::value * RG;
@@ -542,24 +553,68 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const 
     }
     static_for<RG>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      direct_tile(p, d, acc[b0 + i], okp[i], o_off[i], o2_off[i], has_res, res[i], p.out2 ? &o2 : nullptr);
+      direct_tile(p, d, acc[b0 + i], okp[i], o_off[i], o2_off[i], has_res, res[i], p.out2 ? &o2 : nullptr, st, do_stats);
     });
   });
 }
 
-// A wave tile of NT cout groups: group a covers couts [cbase + 32 a, cbase + 32 a + 32).
-template <int MT, int NT, class Decode>
+// A wave tile of NT cout groups: group a covers couts [cbase + 32 a, cbase + 32 a + 32).  BNB =
+// couts per block (for the statistics' block-level sums in `lds`, which every wave of the block
+// must reach).
+template <int MT, int NT, int BNB, class Decode>
 __device__ __forceinline__ void conv_epilogue_direct_groups(const ConvParams& p, const TileCoord& tc,
                                                             const Decode& decode, f32x16 (&acc)[NT][MT],
-                                                            int wm, int cbase, int lane) {
+                                                            int wm, int cbase, int lane, unsigned char* lds) {
+  const bool stats = p.stats != nullptr;
+  float st[NT][32];
   static_for<NT>([&](auto ac) __attribute__((always_inline)) {
     constexpr int a = decltype(ac)::value;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) st[a][j] = 0.f;
     if (cbase + a * 32 < p.Cout) {
       DirectLane dl;
       direct_lane_init(p, cbase + a * 32, lane, dl);
-      conv_epilogue_direct<MT>(p, tc, decode, acc[a], wm, lane, dl);
+      conv_epilogue_direct<MT>(p, tc, decode, acc[a], wm, lane, dl, st[a], stats);
     }
   });
+  if (stats) {
+    // lanes of one half-wave hold the same couts: butterfly over the 32 pixel lanes, then block-
+    // level fp64 sums in LDS (the order in which waves arrive must not show in the fp32
+    // statistics derived from them) and one global fp64 atomic per channel and block
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int j = 0; j < 32; ++j)
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) st[a][j] += __shfl_xor(st[a][j], off, 64);
+    double* sl = reinterpret_cast<double*>(lds);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * BNB; i += blockDim.x) sl[i] = 0.0;
+    __syncthreads();
+    if ((lane & 31) == 0) {
+      const int lhalf = lane >> 5;
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int c = cbase + a * 32 + 16 * q + 8 * lhalf - tc.cout0;
+          if (c + tc.cout0 + 8 <= p.Cout && c + 8 <= BNB) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              unsafeAtomicAdd(&sl[c + j], (double)st[a][8 * q + j]);
+              unsafeAtomicAdd(&sl[BNB + c + j], (double)st[a][16 + 8 * q + j]);
+            }
+          }
+        }
+    }
+    __syncthreads();
+    double* dst = p.stats + (long long)(blockIdx.x % p.stats_rep) * 2 * p.stats_stride;
+    for (int i = threadIdx.x; i < 2 * BNB; i += blockDim.x) {
+      const int which = i / BNB, c = tc.cout0 + (i - which * BNB);
+      const double v = sl[i];
+      if (c < p.Cout && v != 0.0) unsafeAtomicAdd(dst + which * p.stats_stride + c, v);
+    }
+  }
 }
 
 template <int MT, int NT>

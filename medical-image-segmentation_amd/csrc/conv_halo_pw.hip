@@ -232,9 +232,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
   if (direct_epilogue_ok(p)) {
     // straight from the accumulators: no LDS, no waits between the rows' stores
-    DirectLane dl;
-    direct_lane_init(p, tc.cout0 + cgrp * 32, lane, dl);
-    conv_epilogue_direct<MT>(p, tc, dec, acc[0], wm, lane, dl);
+    conv_epilogue_direct_groups<MT, 1, BN>(p, tc, dec, acc, wm, tc.cout0 + cgrp * 32, lane, lds);
     return;
   }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void convT_c64_kernel(const ConvParams p) {
   const unsigned xl0 = lds_a + ((half * 4 + ph_a) * HWD + lrow) * PITCH + lhalf * 16;
 
   // epilogue coefficients live in LDS between patches (registers are full): scale[32] | shift[32]
-  const bool direct = direct_epilogue_ok(p) && !p.residual && !p.out2;
+  const bool direct = direct_epilogue_ok(p) && !p.residual && !p.out2 && !p.stats;
   float* coef = reinterpret_cast<float*>(lds + CT_LDS);
   if (tid < 64) {
     const int c = tid & 31;
@@ -447,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void convT_c64_kernel(const ConvParams p) {
         const bool okp = iy < p.Ho && ix < p.Wo;
         const long long o_off = n * p.out_img_stride + (long long)(2 * iy + ph_a) * p.out_row_stride +
                                 (long long)(2 * ix + pb) * p.out_pix_stride;
-        direct_tile(p, dl, acc[pb][0][b], okp, okp ? o_off : 0, 0, false, nores, nullptr);
+        direct_tile(p, dl, acc[pb][0][b], okp, okp ? o_off : 0, 0, false, nores, nullptr, nullptr, false);
       });
     } else {
       // generic epilogue through LDS scratch that aliases the buffer just computed from

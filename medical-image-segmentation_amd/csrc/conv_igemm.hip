@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
   if (direct_epilogue_ok(p)) {
     // straight from the accumulators: no LDS, no waits between the rows' stores
-    conv_epilogue_direct_groups<MT, NT>(p, tc, dec, acc, wm, tc.cout0 + wn * (NT * 32), lane);
+    conv_epilogue_direct_groups<MT, NT, WARPS_N * NT * 32>(p, tc, dec, acc, wm, tc.cout0 + wn * (NT * 32), lane, lds);
     return;
   }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
   if (direct_epilogue_ok(p)) {
     // straight from the accumulators: no LDS, no waits between the rows' stores
-    conv_epilogue_direct_groups<MT, NT>(p, tc, dec, acc, wm, tc.cout0 + wn * (NT * 32), lane);
+    conv_epilogue_direct_groups<MT, NT, WARPS_N * NT * 32>(p, tc, dec, acc, wm, tc.cout0 + wn * (NT * 32), lane, lds);
     return;
   }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
   if (direct_epilogue_ok(p)) {
     // straight from the accumulators: no LDS, no waits between the rows' stores
-    conv_epilogue_direct_groups<MT, NT>(p, tc, dec, acc, wm, tc.cout0 + wn * (NT * 32), lane);
+    conv_epilogue_direct_groups<MT, NT, WARPS_N * NT * 32>(p, tc, dec, acc, wm, tc.cout0 + wn * (NT * 32), lane, lds);
     return;
   }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const ConvParams p) {
   }
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
   if (direct_epilogue_ok(p)) {
-    conv_epilogue_direct_groups<MT, 1>(p, tc, dec, acc, wave, tc.cout0, lane);
+    conv_epilogue_direct_groups<MT, 1, 32>(p, tc, dec, acc, wave, tc.cout0, lane, lds);
     return;
   }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
