@@ -45,6 +45,7 @@ extern "C" {
 #define MISEG_TILE_NO_DMA 16
 #define MISEG_TILE_NO_HALO 32
 #define MISEG_TILE_SHARED_W 64  /* halo kernels: block-shared weight tiles instead of wave-private rings */
+#define MISEG_TILE_NO_PERSIST 128 /* Cin = 32 layers: one patch per block instead of persistent blocks */
 
 const char* miseg_last_error(void);
 int miseg_version(void);

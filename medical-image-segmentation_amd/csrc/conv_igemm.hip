@@ -764,6 +764,8 @@ int validate_conv(const miseg_conv_desc* d) {
 enum KernelKind { K_REG = 0, K_REG_PRO = 1, K_DMA = 2, K_HALO = 3, K_C32 = 4, K_HALO_PW = 5 };
 
 hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s);
+bool conv_c32p_ok(const ConvParams& p);
+hipError_t launch_conv_c32p(const ConvParams& p, hipStream_t s);
 struct KernelChoice {
   KernelKind kind;
   int cfg;  // 1..7 index into kCfgs; 8..10 halo variants
@@ -919,6 +921,14 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   if (d->scale2) p.vec_ok &= ((uintptr_t)d->scale2 & 15) == 0 && ((uintptr_t)d->shift2 & 15) == 0;
   if (d->act == MISEG_ACT_SOFTMAX || d->act == MISEG_ACT_SIGMOID) p.vec_ok = 0;
   hipError_t e;
+  if (kc.kind == K_C32 && conv_c32p_ok(p) && !(d->tile_hint & MISEG_TILE_NO_PERSIST)) {
+    e = launch_conv_c32p(p, stream);
+    if (e != hipSuccess) {
+      set_error("conv launch failed: %s", hipGetErrorString(e));
+      return MISEG_E_HIP;
+    }
+    return MISEG_OK;
+  }
   if (kc.kind == K_HALO_PW) {
     e = launch_halo_pw(p, grid, stream);
     if (e != hipSuccess) {

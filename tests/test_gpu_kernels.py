@@ -161,6 +161,28 @@ def test_conv_epilogues(env):
     np.testing.assert_allclose(got2, np.maximum((base + resb) * s2 + t2, 0), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("shape", [(3, 250, 400, 32, 32), (1, 37, 70, 32, 24), (2, 8, 32, 32, 8)])
+def test_conv_c32_persistent(env, shape):
+    """Cin = 32, Cout <= 32 with bf16 output runs on persistent blocks (weights in registers,
+    double-buffered halo, several patches per block); it accumulates the taps in the same order as
+    the one-patch kernel (hint 128) and must agree with it bit for bit, and with the oracle."""
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(41)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    wt = bf16_round(rng.normal(0, 0.1, (3, 3, cin, cout)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.5, cout).astype(np.float32)
+    base = ref_conv(x, wt, 1, 1)
+    for kw in (dict(), dict(scale=sc, shift=sh, act=1), dict(shift=sh, in_extra_c=32, out_extra_c=32)):
+        got, _ = run_conv(env, x, wt, 1, 1, **kw)
+        old, _ = run_conv(env, x, wt, 1, 1, tile_hint=128, **kw)
+        np.testing.assert_array_equal(got, old)
+        want = base * kw.get("scale", 1.0) + kw.get("shift", 0.0)
+        if kw.get("act"):
+            want = np.maximum(want, 0)
+        np.testing.assert_allclose(got, want, rtol=1e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("k,pad", [(1, 0), (3, 1)])
 def test_conv_prologue(env, k, pad):
     """BatchNorm+ReLU applied to the operand; padded taps must stay zero."""

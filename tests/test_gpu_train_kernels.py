@@ -312,7 +312,8 @@ def test_adam_keras_form(env):
 
 @pytest.mark.parametrize("case", [(2, 16, 40, 64, 128, 3, False), (1, 9, 33, 64, 64, 3, False),
                                   (2, 12, 20, 32, 32, 3, False), (1, 8, 16, 64, 32, 1, False),
-                                  (2, 8, 24, 64, 64, 4, True), (1, 10, 20, 128, 160, 3, False)])
+                                  (2, 8, 24, 64, 64, 4, True), (1, 10, 20, 128, 160, 3, False),
+                                  (3, 250, 400, 32, 32, 3, False)])
 def test_conv_epilogue_statistics(env, case):
     """miseg_conv_desc.stats: per-channel sum / sum of squares of the STORED bf16 output, spread over
     replicas, then miseg_bn_finalize == miseg_bn_stats_fwd on the same tensor (mean/var to fp32
