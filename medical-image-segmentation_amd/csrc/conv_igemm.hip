@@ -766,6 +766,8 @@ enum KernelKind { K_REG = 0, K_REG_PRO = 1, K_DMA = 2, K_HALO = 3, K_C32 = 4, K_
 hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s);
 bool conv_c32p_ok(const ConvParams& p);
 hipError_t launch_conv_c32p(const ConvParams& p, hipStream_t s);
+bool conv_stem7_ok(const ConvParams& p);
+hipError_t launch_conv_stem7(ConvParams p, hipStream_t s);
 struct KernelChoice {
   KernelKind kind;
   int cfg;  // 1..7 index into kCfgs; 8..10 halo variants
@@ -813,9 +815,22 @@ static KernelChoice choose_kernel(const miseg_conv_desc* d) {
   return {K_REG, cfg};
 }
 
+static void fill_params(const miseg_conv_desc* d, ConvParams& p);
+
 // Name of the kernel instantiation launch_conv() picks for `d`, as rocprofv3 prints it.
 void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
   const KernelChoice kc = choose_kernel(d);
+  ConvParams pp;
+  fill_params(d, pp);
+  const bool persist = !(d->tile_hint & MISEG_TILE_NO_PERSIST);
+  if ((d->tile_hint & 15) == 0 && persist && conv_stem7_ok(pp)) {
+    snprintf(buf, len, "conv_stem7_kernel");
+    return;
+  }
+  if (kc.kind == K_C32 && persist && conv_c32p_ok(pp)) {
+    snprintf(buf, len, "conv3x3_c32p_kernel");
+    return;
+  }
   static const char* shapes[] = {"2, 2, 2, 2", "4, 1, 2, 2", "4, 1, 2, 1", "2, 2, 1, 1",
                                  "4, 1, 1, 2", "4, 1, 1, 1", "2, 2, 1, 2"};
   static const char* halos[] = {"8, 32, 4, 2, 2, 2, 2", "8, 32, 4, 2, 2, 1, 2", "8, 16, 4, 2, 1, 2, 2",
@@ -870,6 +885,20 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.stats_rep = d->stats_replicas;
   p.stats_stride = d->stats_stride;
   p.M = d->N * d->Ho * d->Wo;
+  auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
+    return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
+  };
+  p.vec_ok = 1;
+  if (d->out)
+    p.vec_ok &= al(d->out, d->out_pix_stride, d->out_row_stride, d->out_img_stride,
+                   d->out_dtype == MISEG_DT_F32 ? 3 : 7);
+  if (d->out2)
+    p.vec_ok &= al(d->out2, d->out2_pix_stride, d->out2_row_stride, d->out2_img_stride, 7);
+  if (d->residual)
+    p.vec_ok &= al(d->residual, d->res_pix_stride, d->res_row_stride, d->res_img_stride,
+                   d->res_dtype == MISEG_DT_F32 ? 3 : 7);
+  if (d->scale2) p.vec_ok &= ((uintptr_t)d->scale2 & 15) == 0 && ((uintptr_t)d->shift2 & 15) == 0;
+  if (d->act == MISEG_ACT_SOFTMAX || d->act == MISEG_ACT_SIGMOID) p.vec_ok = 0;
 }
 
 int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
@@ -906,21 +935,15 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   }
   // the wave-private-ring kernel computes the four transpose-conv phases in one block
   const dim3 grid(p.mtiles * p.ntiles * ((d->transposed && kc.kind != K_HALO_PW) ? 4 : 1), 1, 1);
-  auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
-    return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
-  };
-  p.vec_ok = 1;
-  if (d->out)
-    p.vec_ok &= al(d->out, d->out_pix_stride, d->out_row_stride, d->out_img_stride,
-                   d->out_dtype == MISEG_DT_F32 ? 3 : 7);
-  if (d->out2)
-    p.vec_ok &= al(d->out2, d->out2_pix_stride, d->out2_row_stride, d->out2_img_stride, 7);
-  if (d->residual)
-    p.vec_ok &= al(d->residual, d->res_pix_stride, d->res_row_stride, d->res_img_stride,
-                   d->res_dtype == MISEG_DT_F32 ? 3 : 7);
-  if (d->scale2) p.vec_ok &= ((uintptr_t)d->scale2 & 15) == 0 && ((uintptr_t)d->shift2 & 15) == 0;
-  if (d->act == MISEG_ACT_SOFTMAX || d->act == MISEG_ACT_SIGMOID) p.vec_ok = 0;
   hipError_t e;
+  if ((d->tile_hint & 15) == 0 && !(d->tile_hint & MISEG_TILE_NO_PERSIST) && conv_stem7_ok(p)) {
+    e = launch_conv_stem7(p, stream);
+    if (e != hipSuccess) {
+      set_error("conv launch failed: %s", hipGetErrorString(e));
+      return MISEG_E_HIP;
+    }
+    return MISEG_OK;
+  }
   if (kc.kind == K_C32 && conv_c32p_ok(p) && !(d->tile_hint & MISEG_TILE_NO_PERSIST)) {
     e = launch_conv_c32p(p, stream);
     if (e != hipSuccess) {

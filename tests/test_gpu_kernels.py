@@ -183,6 +183,46 @@ def test_conv_c32_persistent(env, shape):
         np.testing.assert_allclose(got, want, rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("shape", [(2, 300, 520, 64), (1, 38, 70, 64), (1, 16, 64, 40)])
+def test_conv_stem_persistent(env, shape):
+    """The 7x7 stride-2 stem in the plan builder's form (7x1, vertical stride 2, windows of
+    8 pixels x 4 channels every 2 pixels of a zero-padded input) on the persistent stem kernel:
+    against the generic kernel (hint 128) and against the oracle's 7x7 stride-2 convolution."""
+    from oracle import ops_np
+    L, lib, dev = env
+    n, h, w, cout = shape
+    rng = np.random.default_rng(53)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, 3)))
+    k = bf16_round(rng.normal(0, 0.1, (7, 7, 3, cout)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.5, cout).astype(np.float32)
+    want = np.maximum(ops_np.conv2d(x, k, stride=2, pad=3) * sc + sh, 0)
+    padded = np.zeros((n, h + 6, w + 8, 4), np.float32)
+    padded[:, 3:3 + h, 3:3 + w, :3] = x
+    wk = np.zeros((cout, 7, 1, 8, 4), np.float32)
+    wk[:, :, 0, :7, :3] = k.transpose(3, 0, 1, 2)
+    xin, wt = dev_bf16(padded, dev), dev_bf16(wk.reshape(cout, 7, 1, 32), dev)
+    scd, shd = dev_f32(sc, dev), dev_f32(sh, dev)
+    outs = []
+    for hint in (0, 128):
+        out = torch.full((n, h // 2, w // 2, cout), 7.0, dtype=torch.bfloat16, device=dev)
+        d = L.ConvDesc()
+        d.inp, d.weight, d.out = xin.data_ptr(), wt.data_ptr(), out.data_ptr()
+        d.N, d.H, d.W, d.Cin = n, h + 6, w // 2, 32
+        d.Ho, d.Wo, d.Cout = h // 2, w // 2, cout
+        d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = 7, 1, 2, 1, 0, 0
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = 8, (w + 8) * 4, (h + 6) * (w + 8) * 4
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * (w // 2), cout * (w // 2) * (h // 2)
+        d.scale, d.shift, d.act, d.out_dtype, d.temperature = scd.data_ptr(), shd.data_ptr(), 1, L.DT_BF16, 1.0
+        d.tile_hint = hint
+        L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+        torch.cuda.synchronize()
+        outs.append(out.float().cpu().numpy())
+    np.testing.assert_allclose(outs[0], want, rtol=1e-2, atol=2e-2)
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-2, atol=1e-2)   # summation order may differ
+    assert (outs[0] != outs[1]).mean() < 0.02
+
+
 @pytest.mark.parametrize("k,pad", [(1, 0), (3, 1)])
 def test_conv_prologue(env, k, pad):
     """BatchNorm+ReLU applied to the operand; padded taps must stay zero."""
