@@ -45,7 +45,7 @@ extern "C" {
 #define MISEG_TILE_NO_DMA 16
 #define MISEG_TILE_NO_HALO 32
 #define MISEG_TILE_SHARED_W 64  /* halo kernels: block-shared weight tiles instead of wave-private rings */
-#define MISEG_TILE_NO_PERSIST 128 /* Cin = 32 layers: one patch per block instead of persistent blocks */
+#define MISEG_TILE_NO_PERSIST 128 /* Cin = 32 layers and the stem: one patch per block instead of persistent blocks */
 
 const char* miseg_last_error(void);
 int miseg_version(void);
@@ -106,7 +106,10 @@ typedef struct miseg_conv_desc {
   float temperature;       /* MISEG_ACT_SOFTMAX: logits are divided by it */
   int32_t collapse_value;  /* value written for the winning channel (127) */
   int32_t tile_hint;       /* 0 = choose automatically; low 4 bits = tile config 1..15,
-                              | MISEG_TILE_NO_DMA forces the register-staged path (tests) */
+                              | MISEG_TILE_NO_DMA forces the register-staged path,
+                              | MISEG_TILE_NO_HALO / _SHARED_W / _NO_PERSIST keep a layer off the
+                              halo-resident / wave-private-ring / persistent kernels (tests compare
+                              the variants with each other) */
   /* Optional per-channel statistics of the stored bf16 output for a following training-mode
    * BatchNormalization (fused into the epilogue instead of a second pass over the tensor):
    * double[stats_replicas + 1][2][stats_stride], zeroed by the caller; the kernel ADDS sum(v) to
