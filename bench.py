@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--train-warmup", type=int, default=1)
     ap.add_argument("--per-op", action="store_true", help="print a per-kernel table to stderr")
+    ap.add_argument("--residual-bf16", action="store_true",
+                    help="keep the ResNet residual stream in bf16 (Engine(residual_bf16=True)); not the default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +174,8 @@ def main():
     weights = build_weights(graph)
     # Images are independent: each plan owns its buffers and runs on its own stream, so the tail of
     # one plan's kernel overlaps the head of another's.
-    engs = [engine.Engine(graph, weights, batch=args.batch, device=str(dev)) for _ in range(args.streams)]
+    engs = [engine.Engine(graph, weights, batch=args.batch, device=str(dev), residual_bf16=args.residual_bf16)
+            for _ in range(args.streams)]
     streams = [torch.cuda.Stream(dev) for _ in range(args.streams)]
     eng = engs[0]
     for i, e in enumerate(engs):
@@ -264,9 +267,9 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {"workload": "%s %s inference %dx%dx3, %d classes, random-init weights, "
-                                   "%d images per GPU per step (%d concurrent plans of %d images)" %
+                                   "%d images per GPU per step (%d concurrent plans of %d images)%s" %
                                    (args.encoder, args.decoder, h, w, args.classes, per_step, args.streams,
-                                    args.batch),
+                                    args.batch, ", bf16 residual stream" if args.residual_bf16 else ""),
                        "images_per_step_per_gpu": per_step,
                        "parallelism": "independent images per GPU, no collective"},
             "roofline": {

@@ -38,6 +38,17 @@ def make_inputs(n, h, w, seed=1234):
 
 @pytest.mark.parametrize("enc,dec,hw,n,classes", CONFIGS)
 def test_engine_vs_oracle(enc, dec, hw, n, classes):
+    check_engine(enc, dec, hw, n, classes)
+
+
+def test_engine_bf16_residual_stream():
+    """Engine(residual_bf16=True) keeps the ResNet residual stream in bf16 (faster, off by
+    default); it must clear the same bars."""
+    check_engine("resnet34", "U-Net", (96, 64), 1, 3, residual_bf16=True)
+    check_engine("resnet18", "Linknet", (64, 64), 1, 3, residual_bf16=True)
+
+
+def check_engine(enc, dec, hw, n, classes, **engine_options):
     import miseg_amd
     from miseg_amd import engine, netspec
     from oracle import nets, ops_torch, post, losses
@@ -59,7 +70,7 @@ def test_engine_vs_oracle(enc, dec, hw, n, classes):
         weights[head]["bias"] = weights[head]["bias"] * np.float32(1.5 / spread)
     taps = {}
     want = ops_torch.to_numpy(nets.forward(ops_torch, enc, dec, weights, x, activation=act, taps=taps))
-    eng = engine.Engine(g, weights, batch=n)
+    eng = engine.Engine(g, weights, batch=n, **engine_options)
     got = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
     torch.cuda.synchronize()
     # intermediate tensors first: they localise a failure
