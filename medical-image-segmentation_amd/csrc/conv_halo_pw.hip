@@ -240,6 +240,225 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same kernel for 32 < Cout <= 64 (stage 1 of the ResNets, the decoder's 128 -> 64 layer): two
+// cout groups cannot feed four waves, so the waves of a block split K as well.  Wave (g, kh)
+// computes cout group g from HALF of every tap's 64-channel slice (channels 32 kh .. 32 kh + 31)
+// for all 8 pixel rows; its weight steps are [32 couts][32 k] = 2 KB, streamed through a private
+// ring of four slots three steps ahead (counted vmcnt waits), which costs the same 32 KB of LDS
+// as the two-slot rings above.  At the end the two K halves of a cout group swap half of their
+// accumulators through LDS (the halo and the rings are dead by then) and each finishes four
+// pixel rows.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int KS_WST = 32 * 64;   // one ring slot: [32 couts][32 k] bf16
+static_assert(PW_HALO_BYTES + 4 * 4 * KS_WST == PW_LDS, "same LDS budget as the full-K kernel");
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_ks_kernel(const ConvParams p) {
+  constexpr int TH = PW_TH, TW = PW_TW, HWD = PW_HWD, PITCH = PW_PITCH, MT = 8;
+  constexpr int TAPS = 9, TAPW = 3;
+  constexpr int BM = TH * TW, BN = 64;
+  constexpr int NHW = PW_NHI / 4;
+  constexpr int WOFF = PW_HALO_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[PW_LDS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 1;      // cout group
+  const int kh = wave >> 1;     // K half
+  const TileCoord tc = tile_coord<BM, BN, false>(p);
+  const int mtile = tc.m0 / BM;
+  const int per_img = p.tiles_y * p.tiles_x;
+  const int n = mtile / per_img;
+  const int trem = mtile - n * per_img;
+  const int tyi = trem / p.tiles_x;
+  const int y0 = tyi * TH;
+  const int x0 = (trem - tyi * p.tiles_x) * TW;
+  const int nchunk = p.Cin >> 6;
+  const int nsteps = nchunk * TAPS;
+
+  const unsigned char* zero_src = g_zero_line;
+  const unsigned char* img = reinterpret_cast<const unsigned char*>(p.in + n * p.in_img_stride);
+  int h_off[NHW];
+#pragma unroll
+  for (int j = 0; j < NHW; ++j) {
+    const int o = (4 * j + wave) * 1024 + lane * 16;
+    const int hr = o / PITCH;
+    const int sl = (o - hr * PITCH) >> 4;
+    const int hy = hr / HWD;
+    const int hx = hr - hy * HWD;
+    const int iy = y0 - 1 + hy;
+    const int ix = x0 - 1 + hx;
+    const bool ok = hr < PW_HROWS && sl < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    h_off[j] = ok ? (iy * p.in_row_stride + ix * p.in_pix_stride + sl * 8) * 2 : -1;
+  }
+  // weight sources: request j of a step fills ring rows [16j, 16j + 16) (64 B each; row = cout of
+  // this wave's group, rows past Cout repeat the last cout: their results are never stored); the
+  // 16-byte chunk index is XOR-swizzled with the row on the source side
+  int w_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = j * 16 + (lane >> 2);
+    int co = tc.cout0 + wn * 32 + row;
+    co = co < p.Cout ? co : p.Cout - 1;
+    w_off[j] = (co * TAPS * p.Cin + kh * 32 + ((lane & 3) ^ ((row >> 2) & 3)) * 8) * 2;
+  }
+  const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(tc.wbase);
+  unsigned char* wring = lds + WOFF + wave * (4 * KS_WST);
+
+  auto issue_halo = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < NHW; ++j) {
+      const unsigned char* src = h_off[j] >= 0 ? img + (unsigned)h_off[j] + chunk * 128 : zero_src;
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)src,
+          (__attribute__((address_space(3))) void*)(lds + (4 * j + wave) * 1024), 16, 0, 0);
+    }
+  };
+  int issued = 0, c_tap = 0, c_chunk = 0;   // weight steps requested so far; the next one
+  auto issue_next = [&]() {
+    if (issued >= nsteps) return;
+    const int koff = (c_tap * p.Cin + c_chunk * 64) * 2;
+    unsigned char* dst = wring + (issued & 3) * KS_WST;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(wsrc + (unsigned)w_off[j] + koff),
+          (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, 0, 0);
+    ++issued;
+    if (++c_tap == TAPS) {
+      c_tap = 0;
+      ++c_chunk;
+    }
+  };
+
+  f32x16 acc[1][MT];
+  zero_acc<MT, 1>(acc);
+  const int lrow = lane & 31;
+  const int lhalf = lane >> 5;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  // pixel fragment (b, dy, dx, s) = xl + ((b + dy) * HWD + dx) * PITCH + s * 32
+  const unsigned xl = (unsigned)(unsigned long long)(lds_byte*)lds + lrow * PITCH + lhalf * 16 + kh * 64;
+  const unsigned wr = (unsigned)(unsigned long long)(lds_byte*)wring;
+  int wlane[2];
+#pragma unroll
+  for (int sidx = 0; sidx < 2; ++sidx) wlane[sidx] = swz64(lrow, sidx * 2 + lhalf);
+  bf16x8 xf[MT], wf[2];
+
+  issue_halo(0);
+  issue_next();
+  issue_next();
+  issue_next();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int g = 0;   // global step = ring position of the current tap
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const bool more = chunk + 1 < nchunk;
+    static_for<MT>([&](auto bc) __attribute__((always_inline)) {
+      constexpr int b = decltype(bc)::value;
+      ds_read_b128_at<b * HWD * PITCH>(xf[b], xl);
+    });
+    {
+      const unsigned w0 = wr + (g & 3) * KS_WST;
+      ds_read_b128_at<0>(wf[0], w0 + wlane[0]);
+      ds_read_b128_at<0>(wf[1], w0 + wlane[1]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(xf[0]), "+v"(xf[1]), "+v"(xf[2]), "+v"(xf[3]), "+v"(xf[4]), "+v"(xf[5]),
+                   "+v"(xf[6]), "+v"(xf[7]), "+v"(wf[0]), "+v"(wf[1]));
+
+    static_for<TAPS>([&](auto tc_) __attribute__((always_inline)) {
+      constexpr int tap = decltype(tc_)::value;
+      constexpr bool last = tap == TAPS - 1;
+      const unsigned wnxt = wr + ((g + 1) & 3) * KS_WST;
+      issue_next();                            // step g + 3 into the slot step g - 1 has left
+      const int ahead = issued - (g + 2);      // steps requested after step g + 1
+      static_for<2>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int sidx = decltype(kc)::value;
+        constexpr int ntap = tap + (sidx + 1) / 2, ns = (sidx + 1) % 2;
+        constexpr bool has_x = ntap < TAPS;
+        constexpr bool has_w = !last;            // the chunk top reads its first fragments itself
+        constexpr bool first = tap == 0 && sidx == 0;
+        constexpr bool prev_w = sidx == 0 ? tap != 0 : !last;   // did the previous sub-step read ahead a weight fragment?
+        static_for<MT>([&](auto bc) __attribute__((always_inline)) {
+          constexpr int b = decltype(bc)::value;
+          if constexpr (!first) {
+            constexpr int younger = (MT - 1 - b) + (prev_w ? 1 : 0) + (has_x ? b : 0);
+            lgkm_wait<younger>(xf[b]);
+          }
+          acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[sidx], xf[b], acc[0][b], 0, 0, 0);
+          if constexpr (has_x)
+            ds_read_b128_at<((b + ntap / TAPW) * HWD + ntap % TAPW) * PITCH + ns * 32>(xf[b], xl);
+          if constexpr (b == MT - 1 && has_w) {
+            if constexpr (sidx == 0) {
+              // step g + 1 must have landed: all but the requests of the steps after it
+              if (ahead >= 2)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+              else if (ahead == 1)
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+              else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            ds_read_b128_at<0>(wf[sidx], wnxt + wlane[sidx]);
+          }
+        });
+      });
+      ++g;
+    });
+    if (more) {
+      __syncthreads();   // every wave is done with this chunk's halo
+      issue_halo(chunk + 1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // halo and the requested weight steps
+      __syncthreads();
+    }
+  }
+  // ---- the two K halves of a cout group swap half of their accumulators: (g, 0) finishes pixel
+  //      rows 0-3, (g, 1) rows 4-7 ----
+  __syncthreads();   // halo and rings are dead
+  {
+    float4* mine = reinterpret_cast<float4*>(lds) + wave * (16 * 64);
+    const float4* theirs = reinterpret_cast<const float4*>(lds) + (wave ^ 2) * (16 * 64);
+    static_for<16>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int bq = i >> 2, q = i & 3;
+      // give away the rows the partner finishes: kh == 0 gives rows 4-7, kh == 1 gives rows 0-3
+      const f32x16& t0 = acc[0][bq], &t1 = acc[0][4 + bq];
+      const float4 v = kh == 0 ? make_float4(t1[4 * q], t1[4 * q + 1], t1[4 * q + 2], t1[4 * q + 3])
+                               : make_float4(t0[4 * q], t0[4 * q + 1], t0[4 * q + 2], t0[4 * q + 3]);
+      mine[i * 64 + lane] = v;
+    });
+    __syncthreads();
+    static_for<16>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int bq = i >> 2, q = i & 3;
+      const float4 v = theirs[i * 64 + lane];
+      // keep rows 0-3 (kh == 0) or 4-7 (kh == 1) in acc[0][0..3]
+      if (kh == 1) {
+        acc[0][bq][4 * q] = acc[0][4 + bq][4 * q];
+        acc[0][bq][4 * q + 1] = acc[0][4 + bq][4 * q + 1];
+        acc[0][bq][4 * q + 2] = acc[0][4 + bq][4 * q + 2];
+        acc[0][bq][4 * q + 3] = acc[0][4 + bq][4 * q + 3];
+      }
+      acc[0][bq][4 * q] += v.x;
+      acc[0][bq][4 * q + 1] += v.y;
+      acc[0][bq][4 * q + 2] += v.z;
+      acc[0][bq][4 * q + 3] += v.w;
+    });
+  }
+  f32x16 fin[1][4] = {{acc[0][0], acc[0][1], acc[0][2], acc[0][3]}};
+  const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+  if (direct_epilogue_ok(p)) {
+    __syncthreads();   // the statistics' block sums alias the swap regions
+    conv_epilogue_direct_groups<4, 1, BN>(p, tc, dec, fin, kh, tc.cout0 + wn * 32, lane, lds);
+    return;
+  }
+  __syncthreads();   // the epilogue regions alias the swap regions
+  conv_epilogue<2, 4, 1>(p, tc, dec, fin, lds, kh, wn, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Conv2DTranspose(4, 2, 'same') with 64 input channels and <= 32 output channels (the last
 // transpose of the U-Net decoder, 64 -> 32 at full resolution): 1 MAC per 3 bytes of traffic, so
 // the layer is bound by HBM and, in the kernel above, by how it stores: a wave that owns ONE
@@ -477,6 +696,10 @@ hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s) {
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int blocks = p.mtiles < cus ? p.mtiles : cus;
     hipLaunchKernelGGL(convT_c64_kernel, dim3(blocks), dim3(256), 0, s, p);
+    return hipGetLastError();
+  }
+  if (!p.transposed && p.Cout <= 64) {
+    hipLaunchKernelGGL(conv3x3_halo_ks_kernel, grid, dim3(256), 0, s, p);
     return hipGetLastError();
   }
   if (p.transposed)

@@ -786,7 +786,7 @@ static KernelChoice choose_kernel(const miseg_conv_desc* d) {
                       !(d->tile_hint & MISEG_TILE_NO_HALO);
   if (c32_ok && (hint == 0 || hint == 14)) return {K_C32, 14};
   // wave-private weight rings: per-lane source offsets are 32-bit byte offsets from the image base
-  const bool pw_ok = hint == 0 && (d->Cout > 64 || d->transposed) && !(d->tile_hint & MISEG_TILE_SHARED_W) &&
+  const bool pw_ok = hint == 0 && (d->Cout > 32 || d->transposed) && !(d->tile_hint & MISEG_TILE_SHARED_W) &&
                      (long long)d->H * d->in_row_stride * 2 < (1ll << 31) &&
                      (long long)d->Cout * 16 * d->Cin * 2 < (1ll << 31);
   const bool convt_ok = !pro && d->transposed && (d->Cin & 63) == 0 &&
@@ -840,6 +840,8 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
     snprintf(buf, len, "conv3x3_c32_kernel<8, 32>");
   else if (kc.kind == K_HALO_PW && d->transposed && d->Cin == 64 && d->Cout <= 32 && !d->stats)
     snprintf(buf, len, "convT_c64_kernel");
+  else if (kc.kind == K_HALO_PW && !d->transposed && d->Cout <= 64)
+    snprintf(buf, len, "conv3x3_halo_ks_kernel");
   else if (kc.kind == K_HALO_PW)
     snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, %s>", d->transposed ? "true" : "false");
   else if (kc.kind == K_HALO)
@@ -920,7 +922,7 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     p.tiles_y = (d->Ho + 7) / 8;
     p.tiles_x = (d->Wo + 31) / 32;
     p.mtiles = d->N * p.tiles_y * p.tiles_x;
-    p.ntiles = d->transposed ? (d->Cout + 31) / 32 : (d->Cout + 127) / 128;
+    p.ntiles = d->transposed ? (d->Cout + 31) / 32 : (d->Cout <= 64 ? 1 : (d->Cout + 127) / 128);
   } else if (kc.kind == K_HALO) {
     const int tw = (cfg == 10 || cfg == 13) ? 16 : 32;
     const int bn = cfg == 15 ? 32 : ((cfg == 9 || cfg == 12) ? 64 : 128);

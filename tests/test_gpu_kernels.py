@@ -116,6 +116,8 @@ CASES = [
     (1, 20, 70, 64, 96, 3, 1, 1),      # several patches per row, ragged right/bottom edge
     (2, 17, 33, 128, 128, 3, 1, 1),    # two channel chunks, odd sizes
     (1, 8, 32, 192, 64, 3, 1, 1),      # exactly one patch, three chunks
+    (2, 50, 70, 128, 64, 3, 1, 1),     # Cout <= 64: waves split K; two chunks, ragged patches
+    (1, 33, 40, 192, 48, 3, 1, 1),     # the same with a ragged cout group
 ]
 
 
