@@ -42,6 +42,7 @@ extern "C" {
 #define MISEG_ACT_SOFTMAX 2 /* over Cout (<= 4), fp32 output, optional u8 collapse */
 #define MISEG_ACT_SIGMOID 3
 
+#define MISEG_CONV_DGRAD_T 2 /* miseg_conv_desc.transposed: data gradient of the transpose convolution */
 #define MISEG_TILE_NO_DMA 16
 #define MISEG_TILE_NO_HALO 32
 #define MISEG_TILE_SHARED_W 64  /* halo kernels: block-shared weight tiles instead of wave-private rings */
@@ -67,11 +68,19 @@ int miseg_device_check(void);
  *   out  = act(v)                           (dtype out_dtype; skipped if out == NULL)
  *   out2 = relu(v*scale2[co] + shift2[co])  (bf16; skipped if out2 == NULL)
  *
- * transposed != 0 selects Conv2DTranspose(kernel 4, stride 2, 'same'): the call
+ * transposed == 1 selects Conv2DTranspose(kernel 4, stride 2, 'same'): the call
  * computes the four output phases (a,b) in {0,1}^2 as 2x2 convolutions,
  * out[n, 2y+a, 2x+b, co]; `weight` then holds [4][Cout][2][2][Cin] and
  * KH = KW = 2, strides 1, Ho = H, Wo = W; the out, out2 and res strides describe the
  * full-resolution (2H x 2W) tensor.
+ *
+ * transposed == MISEG_CONV_DGRAD_T is the data gradient of that layer: `in` is the
+ * gradient at its output (N, 2H, 2W, Cin; the in strides describe that tensor),
+ * H, W, Ho, Wo are the dimensions of the result, KH = KW = 2, strides 1, and
+ *   acc[n,i,j,co] = sum_{a,b,dy,dx,ci} in[n, 2(i+1-a-dy)+a, 2(j+1-b-dx)+b, ci]
+ *                                      * Wt[(a,b)][co][dy][dx][ci]
+ * with `weight` = [4][Cout][2][2][Cin] (the forward layer's phase weights with its
+ * two channel axes exchanged).  Cin % 64 == 0; the epilogue is that of a plain convolution.
  *
  * weight layout: bf16 [Cout][KH][KW][Cin], Cin contiguous.  Cin % 32 == 0.
  */

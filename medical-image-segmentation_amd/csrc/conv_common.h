@@ -56,6 +56,7 @@ struct ConvParams {
   int tiles_y, tiles_x;  // halo kernel: output patches per image
   double* stats;         // optional per-channel sum / sum of squares of the stored bf16 output
   int stats_rep, stats_stride;
+  int dgrad_t;           // data gradient of Conv2DTranspose(4, 2): `in` is dY, taps run over its four phase lattices
 };
 
 // 16 zero bytes x 8: the source of LDS-DMA loads for taps that fall outside the image.

@@ -41,13 +41,21 @@ static_assert(2 * PW_LDS <= 160 * 1024, "two blocks per CU");
 
 }  // namespace
 
-template <int WARPS_M, int MT, bool CONVT>
+// DGT: the data gradient of Conv2DTranspose(4, 2, 'same').  dX[i, j] sums, over the four output
+// phases (a, b) and their 2x2 taps (dy, dx), dY[2 (i + 1 - a - dy) + a, 2 (j + 1 - b - dx) + b]:
+// per phase a 2x2 convolution over the lattice of dY pixels of that phase.  The chunk loop runs
+// over (phase, 64-channel chunk) pairs: the halo of a pair is the lattice view of dY (pixel and
+// row strides doubled, origin shifted by the phase), the phase's taps sit at halo offsets
+// (1 - a) + (1 - dy), (1 - b) + (1 - dx), of which the phase part moves the fragment base and
+// the tap part is an immediate.  Weights: [phase][cout][tap][cin].
+template <int WARPS_M, int MT, bool CONVT, bool DGT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParams p) {
+  static_assert(!(CONVT && DGT), "one mode");
   constexpr int TH = PW_TH, TW = PW_TW, HWD = PW_HWD, PITCH = PW_PITCH;
   constexpr int WARPS_N = 4 / WARPS_M;
   static_assert(WARPS_M == 1 && MT == TH, "a wave owns all 8 rows of the patch");
-  constexpr int TAPS = CONVT ? 4 : 9;
-  constexpr int TAPW = CONVT ? 2 : 3;
+  constexpr int TAPS = (CONVT || DGT) ? 4 : 9;
+  constexpr int TAPW = (CONVT || DGT) ? 2 : 3;
   constexpr int BM = TH * TW;
   constexpr int BN = CONVT ? 32 : WARPS_N * 32;   // transpose-conv: the four waves are the four phases
   constexpr int NHW = PW_NHI / 4;                 // halo wave-instructions per wave
@@ -76,7 +84,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   const int tyi = trem / p.tiles_x;
   const int y0 = tyi * TH;
   const int x0 = (trem - tyi * p.tiles_x) * TW;
-  const int nchunk = p.Cin >> 6;
+  const int nck = p.Cin >> 6;                  // 64-channel chunks
+  const int nchunk = DGT ? 4 * nck : nck;      // halo loads: (phase, chunk) pairs for the data gradient
+  constexpr int LAT = DGT ? 2 : 1;             // dY lattice: every second pixel and row
 
   const unsigned char* zero_src = g_zero_line;
   const unsigned char* img = reinterpret_cast<const unsigned char*>(p.in + n * p.in_img_stride);
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
     const int iy = y0 - 1 + hy;
     const int ix = x0 - 1 + hx;
     const bool ok = hr < PW_HROWS && sl < 8 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    h_off[j] = ok ? (iy * p.in_row_stride + ix * p.in_pix_stride + sl * 8) * 2 : -1;
+    h_off[j] = ok ? (iy * LAT * p.in_row_stride + ix * LAT * p.in_pix_stride + sl * 8) * 2 : -1;
   }
   // weight sources: instruction j fills ring rows [8j, 8j + 8) (row = cout of this wave's group);
   // the 16-byte chunk index is XOR-swizzled with the row on the SOURCE side (the LDS image of
@@ -114,17 +124,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(tc.wbase);
   unsigned char* wring = lds + WOFF + wave * (2 * PW_WST);
 
+  // byte offset of halo load v inside a pixel's row of the source (and the phase's origin)
+  auto chunk_src = [&](int v) {
+    if (!DGT) return v * 128;
+    const int ph = v / nck, ck = v - ph * nck;
+    return ((ph >> 1) * p.in_row_stride + (ph & 1) * p.in_pix_stride + ck * 64) * 2;
+  };
   auto issue_halo = [&](int chunk) {
+    const int coff = chunk_src(chunk);
 #pragma unroll
     for (int j = 0; j < NHW; ++j) {
-      const unsigned char* src = h_off[j] >= 0 ? img + (unsigned)h_off[j] + chunk * 128 : zero_src;
+      const unsigned char* src = h_off[j] >= 0 ? img + (unsigned)h_off[j] + coff : zero_src;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)(lds + (4 * j + wave) * 1024), 16, 0, 0);
     }
   };
   auto issue_w = [&](int tap, int chunk, int slot) {
-    const int koff = (tap * p.Cin + chunk * 64) * 2;
+    int koff = (tap * p.Cin + chunk * 64) * 2;
+    if (DGT) {
+      const int ph = chunk / nck, ck = chunk - ph * nck;
+      koff = ((ph * p.Cout * TAPS + tap) * p.Cin + ck * 64) * 2;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned char* src = w_off[j] >= 0 ? wsrc + (unsigned)w_off[j] + koff : zero_src;
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   // sub-steps ahead.  Per sub-step the issue order is x0 .. x7, w; LDS reads return in
   // order, so before MFMA b it is enough that all but the reads issued after x_b have landed.
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
-  const unsigned xl = (unsigned)(unsigned long long)(lds_byte*)xlane;
+  const unsigned xl_base = (unsigned)(unsigned long long)(lds_byte*)xlane;
   const unsigned wr = (unsigned)(unsigned long long)(lds_byte*)wring;
   bf16x8 xf[MT], wf[2];
 #define MISEG_DS_READ(dst, addr, off) ds_read_b128_at<off>(dst, addr)
@@ -166,10 +187,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   int slot0 = 0;   // ring slot of tap 0 of the current chunk
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const bool more = chunk + 1 < nchunk;
+    // data gradient: the phase's part of the tap offsets moves the fragment base
+    unsigned xl = xl_base;
+    if (DGT) {
+      const int ph = chunk / nck;
+      xl += ((1 - (ph >> 1)) * HWD + (1 - (ph & 1))) * PITCH;
+    }
     // fragments of the chunk's first sub-steps
     static_for<MT>([&](auto bc) __attribute__((always_inline)) {
       constexpr int b = decltype(bc)::value;
-      MISEG_DS_READ(xf[b], xl, b * HWD * PITCH);
+      MISEG_DS_READ(xf[b], xl, ((b + (DGT ? 1 : 0)) * HWD + (DGT ? 1 : 0)) * PITCH);
     });
     {
       const unsigned w0 = wr + slot0 * PW_WST;
@@ -209,7 +236,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
           }
           acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1], xf[b], acc[0][b], 0, 0, 0);
           if constexpr (has_x)
-            MISEG_DS_READ(xf[b], xl, ((b + ntap / TAPW) * HWD + ntap % TAPW) * PITCH + nkk * 32);
+            MISEG_DS_READ(xf[b], xl, ((b + (DGT ? 1 - ntap / TAPW : ntap / TAPW)) * HWD +
+                                      (DGT ? 1 - ntap % TAPW : ntap % TAPW)) * PITCH + nkk * 32);
           if constexpr (b == MT - 1 && has_w) {
             if constexpr (kk < 2)
               MISEG_DS_READ(wf[kk & 1], wcur + wlane[kk + 2], 0);
@@ -698,8 +726,12 @@ hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(convT_c64_kernel, dim3(blocks), dim3(256), 0, s, p);
     return hipGetLastError();
   }
-  if (!p.transposed && p.Cout <= 64) {
+  if (!p.transposed && !p.dgrad_t && p.Cout <= 64) {
     hipLaunchKernelGGL(conv3x3_halo_ks_kernel, grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+  }
+  if (p.dgrad_t) {
+    hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, true>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
   }
   if (p.transposed)

@@ -701,6 +701,15 @@ int validate_conv(const miseg_conv_desc* d) {
     MISEG_CHECK_ARG(d->KH == 2 && d->KW == 2 && d->stride_y == 1 && d->stride_x == 1 &&
                         d->Ho == d->H && d->Wo == d->W,
                     "conv: transposed mode needs KH=KW=2, stride 1, Ho=H, Wo=W");
+    if (d->transposed == MISEG_CONV_DGRAD_T) {
+      MISEG_CHECK_ARG((d->Cin & 63) == 0 && !d->in_scale && !d->collapse_out,
+                      "conv: transpose-conv data gradient needs Cin %% 64 == 0 and no operand prologue");
+      MISEG_CHECK_ARG((long long)d->H * 2 * d->in_row_stride * 2 < (1ll << 31) &&
+                          (long long)d->Cout * 16 * d->Cin * 2 < (1ll << 31),
+                      "conv: transpose-conv data gradient: image or weight set too large for 32-bit offsets");
+    } else {
+      MISEG_CHECK_ARG(d->transposed == 1, "conv: transposed must be 0, 1 or MISEG_CONV_DGRAD_T");
+    }
   } else {
     // every output pixel's window must start inside the padded image
     MISEG_CHECK_ARG((d->Ho - 1) * d->stride_y - d->pad_y < d->H &&
@@ -819,6 +828,10 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p);
 
 // Name of the kernel instantiation launch_conv() picks for `d`, as rocprofv3 prints it.
 void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
+  if (d->transposed == MISEG_CONV_DGRAD_T) {
+    snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, false, true>");
+    return;
+  }
   const KernelChoice kc = choose_kernel(d);
   ConvParams pp;
   fill_params(d, pp);
@@ -887,6 +900,7 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.stats_rep = d->stats_replicas;
   p.stats_stride = d->stats_stride;
   p.M = d->N * d->Ho * d->Wo;
+  p.dgrad_t = 0;
   auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
     return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
   };
@@ -908,6 +922,21 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   if (rc != MISEG_OK) return rc;
   ConvParams p;
   fill_params(d, p);
+  if (d->transposed == MISEG_CONV_DGRAD_T) {
+    // dX = sum over the four phase lattices of dY: one launch of the ring kernel in its data-gradient mode
+    p.transposed = 0;
+    p.dgrad_t = 1;
+    p.tiles_y = (d->Ho + 7) / 8;
+    p.tiles_x = (d->Wo + 31) / 32;
+    p.mtiles = d->N * p.tiles_y * p.tiles_x;
+    p.ntiles = (d->Cout + 127) / 128;
+    const hipError_t e2 = launch_halo_pw(p, dim3(p.mtiles * p.ntiles), stream);
+    if (e2 != hipSuccess) {
+      set_error("conv launch failed: %s", hipGetErrorString(e2));
+      return MISEG_E_HIP;
+    }
+    return MISEG_OK;
+  }
   const KernelChoice kc = choose_kernel(d);
   const int cfg = kc.cfg;
   const bool pro = kc.kind == K_REG_PRO;

@@ -342,6 +342,9 @@ class Trainer:
         d.Ho, d.Wo, d.Cout = ho, wo, cout
         d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
         d.in_pix_stride, d.in_row_stride, d.in_img_stride = x.pix, x.pix * x.w, x.pix * x.w * x.h
+        if transposed == 2:                       # data gradient of a transpose conv: x is dY (2ho x 2wo)
+            assert (x.h, x.w) == (2 * ho, 2 * wo)
+            d.H, d.W = ho, wo
         if probs is not None:
             d.out = probs.data_ptr()
             c = probs.shape[-1]
@@ -350,7 +353,7 @@ class Trainer:
         elif out_view is not None:
             d.out, d.out_pix_stride, d.out_row_stride, d.out_img_stride = out_view
         else:
-            oh, ow = (2 * ho, 2 * wo) if transposed else (ho, wo)
+            oh, ow = (2 * ho, 2 * wo) if transposed == 1 else (ho, wo)
             assert (out.h, out.w) == (oh, ow), (out.h, out.w, oh, ow)
             d.out = out.ptr
             d.out_pix_stride, d.out_row_stride, d.out_img_stride = out.pix, out.pix * ow, out.pix * ow * oh
@@ -360,7 +363,7 @@ class Trainer:
             d.residual, d.res_dtype = r.ptr, L.DT_BF16
             d.res_pix_stride, d.res_row_stride, d.res_img_stride = r.pix, r.pix * r.w, r.pix * r.w * r.h
         d.act = act
-        d.transposed = 1 if transposed else 0
+        d.transposed = int(transposed)          # True/1: transpose conv; 2: its data gradient
         d.temperature = temperature
         if stats is not None:
             d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), STAT_REPLICAS, _c32(cout)
@@ -472,8 +475,12 @@ class Trainer:
                 for dy in range(2):
                     for dx in range(2):
                         k[:, 3 - a - 2 * dy, 3 - b - 2 * dx, :co] = v[a * 2 + b, :, dy, dx, :ci].t()
-        self._dgrad_cache[key] = [k]
-        return [k]
+        packs = [k]
+        if _c32(co) % 64 == 0 and co == _c32(co):
+            # phase form for the one-launch data gradient (transposed = 2): [phase][ci][dy][dx][co]
+            packs.append(v[..., :ci].permute(0, 4, 2, 3, 1).to(torch.bfloat16).contiguous())
+        self._dgrad_cache[key] = packs
+        return packs
 
     # ------------------------------------------------------------------ forward (training mode)
     def forward(self, x, momentum_update=True):
@@ -885,12 +892,20 @@ class Trainer:
                            self.G.data_ptr() + 4 * (seg.off + (a * 2 + b) * per_phase), cin, co, 2, 2, 1, 1,
                            1 - a, 1 - b, xin.h, xin.w, dy_t=dy.t)
         src_name = l.inbound[0]
-        wt = self.dgrad_weight(l)[0]
+        packs = self.dgrad_weight(l)
+        wt = packs[0]
         dyv = Act(dy.t, _c32(co), dy.c0)
+        # four phase lattices of dY accumulated in one launch of the ring kernel
+        phased = (len(packs) > 1 and xin.c % 8 == 0 and dy.h * dy.pix * dy.w * 2 < 2 ** 31 and
+                  not os.environ.get("MISEG_NO_PHASED_DGRAD"))
 
         def run(res):
             out = self.new(xin.h, xin.w, xin.c)
-            self.conv(dyv, wt.data_ptr(), xin.c, 4, 4, 2, 2, 1, 1, out, xin.h, xin.w, residual=res)
+            if phased:
+                self.conv(dyv, packs[1].data_ptr(), xin.c, 2, 2, 1, 1, 0, 0, out, xin.h, xin.w, residual=res,
+                          transposed=2)
+            else:
+                self.conv(dyv, wt.data_ptr(), xin.c, 4, 4, 2, 2, 1, 1, out, xin.h, xin.w, residual=res)
             return out
         self._fused_dgrad(grads, src_name, l.name, dy, run)
 

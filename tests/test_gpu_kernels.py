@@ -313,6 +313,48 @@ def test_conv_transpose_c64_persistent(env, shape):
             np.testing.assert_allclose(got, want, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("shape", [(2, 9, 21, 64, 128), (1, 20, 40, 128, 200), (1, 8, 32, 192, 64)])
+def test_conv_transpose_data_gradient(env, shape):
+    """transposed = MISEG_CONV_DGRAD_T: the data gradient of Conv2DTranspose(4, 2, 'same') in one
+    launch (four phase lattices of dY accumulated in the chunk loop) equals the 4x4 stride-2
+    pad-1 convolution of dY with the layer's kernel."""
+    L, lib, dev = env
+    n, h, w, c, ci = shape          # dY: (n, 2h, 2w, c) -> dX: (n, h, w, ci)
+    rng = np.random.default_rng(61)
+    dy = bf16_round(rng.normal(0, 1, (n, 2 * h, 2 * w, c)))
+    k = bf16_round(rng.normal(0, 0.05, (4, 4, c, ci)))            # Keras layout (kh, kw, Cout_T, Cin_T)
+    want = ref_conv(dy, k, 2, 1)
+    ph = np.zeros((2, 2, ci, 2, 2, c), np.float32)
+    for a in range(2):
+        for b in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    ph[a, b, :, ty, tx, :] = k[3 - a - 2 * ty, 3 - b - 2 * tx].T
+    xin, wt = dev_bf16(dy, dev), dev_bf16(ph, dev)
+    res = bf16_round(rng.normal(0, 1, (n, h, w, ci)))
+    rest = dev_bf16(res, dev)
+    for dt, tdt, with_res in ((L.DT_F32, torch.float32, False), (L.DT_BF16, torch.bfloat16, True)):
+        out = torch.zeros((n, h, w, ci), dtype=tdt, device=dev)
+        d = L.ConvDesc()
+        d.inp, d.weight, d.out = xin.data_ptr(), wt.data_ptr(), out.data_ptr()
+        d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, c, h, w, ci
+        d.KH = d.KW = 2
+        d.stride_y = d.stride_x = 1
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = c, c * 2 * w, c * 4 * w * h
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = ci, ci * w, ci * w * h
+        d.out_dtype, d.transposed, d.temperature = dt, 2, 1.0
+        if with_res:
+            d.residual, d.res_dtype = rest.data_ptr(), L.DT_BF16
+            d.res_pix_stride, d.res_row_stride, d.res_img_stride = ci, ci * w, ci * w * h
+        L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+        torch.cuda.synchronize()
+        got = out.float().cpu().numpy()
+        if with_res:
+            np.testing.assert_allclose(got, want + res, rtol=1e-2, atol=3e-2)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
 @pytest.mark.parametrize("classes,act", [(3, 2), (4, 2), (1, 3), (2, 2)])
 def test_conv_head_softmax_collapse(env, classes, act):
     """3x3 head + bias + softmax/sigmoid + strict-argmax collapse in the epilogue."""
