@@ -856,7 +856,7 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
   else if (kc.kind == K_HALO_PW && !d->transposed && d->Cout <= 64)
     snprintf(buf, len, "conv3x3_halo_ks_kernel");
   else if (kc.kind == K_HALO_PW)
-    snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, %s>", d->transposed ? "true" : "false");
+    snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, %s, false>", d->transposed ? "true" : "false");
   else if (kc.kind == K_HALO)
     snprintf(buf, len, "conv3x3_halo_kernel<%s, %s>", halos[kc.cfg - 8], d->transposed ? "true" : "false");
   else if (kc.kind == K_DMA)
