@@ -67,7 +67,7 @@ def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
 def pmc_traffic(kernel, batch, h, w, encoder, decoder):
     """HBM bytes per launch of `kernel` from the committed counter passes (collected with the same
     command at batch 4, 1920x2560, ResNet-34 U-Net); None for any other configuration."""
-    path = os.path.join(ROOT, "profiles", "r01_j_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_k_pmc_traffic.json")
     if not os.path.isfile(path) or (batch, h, w, encoder, decoder) != (4, 1920, 2560, "resnet34", "U-Net"):
         return None
     with open(path) as f:
@@ -285,7 +285,7 @@ def main():
                 "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": pmc_traffic(dom_name, args.batch, h, w, args.encoder, args.decoder),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes), "
-                                "from the committed PMC passes profiles/r01_j_pmc_*.csv",
+                                "from the committed PMC passes profiles/r01_k_pmc_*.csv",
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                 "all_conv_launches": {
                     "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
