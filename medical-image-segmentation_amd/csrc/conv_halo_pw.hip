@@ -48,9 +48,21 @@ static_assert(2 * PW_LDS <= 160 * 1024, "two blocks per CU");
 // row strides doubled, origin shifted by the phase), the phase's taps sit at halo offsets
 // (1 - a) + (1 - dy), (1 - b) + (1 - dx), of which the phase part moves the fragment base and
 // the tap part is an immediate.  Weights: [phase][cout][tap][cin].
+#ifdef MISEG_PW_PROFILE
+// phase timers of wave w of block b (100 MHz ticks): [0] prologue (first halo and weights),
+// [1] arithmetic, [2] halo swaps, [3] epilogue
+__device__ unsigned long long g_pw_prof[1 << 16][4];
+#define PW_TICK(i) do { const unsigned long long t__ = wall_clock64(); pw_t[i] += t__ - pw_last; pw_last = t__; } while (0)
+#else
+#define PW_TICK(i) do { } while (0)
+#endif
+
 template <int WARPS_M, int MT, bool CONVT, bool DGT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParams p) {
   static_assert(!(CONVT && DGT), "one mode");
+#ifdef MISEG_PW_PROFILE
+  unsigned long long pw_t[4] = {0, 0, 0, 0}, pw_last = wall_clock64();
+#endif
   constexpr int TH = PW_TH, TW = PW_TW, HWD = PW_HWD, PITCH = PW_PITCH;
   constexpr int WARPS_N = 4 / WARPS_M;
   static_assert(WARPS_M == 1 && MT == TH, "a wave owns all 8 rows of the patch");
@@ -183,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   issue_w(0, 0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  PW_TICK(0);
 
   int slot0 = 0;   // ring slot of tap 0 of the current chunk
   for (int chunk = 0; chunk < nchunk; ++chunk) {
@@ -248,11 +261,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
       });
     });
     slot0 ^= (TAPS & 1);
+    PW_TICK(1);
     if (more) {
       __syncthreads();   // every wave is done with this chunk's halo
       issue_halo(chunk + 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // halo and the next step's weights
       __syncthreads();
+      PW_TICK(2);
     }
   }
 #undef MISEG_DS_READ
@@ -261,6 +276,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   if (direct_epilogue_ok(p)) {
     // straight from the accumulators: no LDS, no waits between the rows' stores
     conv_epilogue_direct_groups<MT, 1, BN>(p, tc, dec, acc, wm, tc.cout0 + cgrp * 32, lane, lds);
+#ifdef MISEG_PW_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // count the stores' round trip
+    PW_TICK(3);
+    if (lane == 0 && blockIdx.x < (1 << 14))
+      for (int i = 0; i < 4; ++i) g_pw_prof[blockIdx.x * 4 + wave][i] = pw_t[i];
+#endif
     return;
   }
   __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
