@@ -118,6 +118,8 @@ CASES = [
     (1, 8, 32, 192, 64, 3, 1, 1),      # exactly one patch, three chunks
     (2, 50, 70, 128, 64, 3, 1, 1),     # Cout <= 64: waves split K; two chunks, ragged patches
     (1, 33, 40, 192, 48, 3, 1, 1),     # the same with a ragged cout group
+    (2, 11, 37, 64, 40, 3, 1, 1),      # ragged octet inside the second cout group
+    (1, 19, 33, 128, 36, 3, 1, 1),     # Cout not a multiple of 8: generic epilogue after the accumulator swap
 ]
 
 
@@ -163,7 +165,7 @@ def test_conv_epilogues(env):
     np.testing.assert_allclose(got2, np.maximum((base + resb) * s2 + t2, 0), rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("shape", [(3, 250, 400, 32, 32), (1, 37, 70, 32, 24), (2, 8, 32, 32, 8)])
+@pytest.mark.parametrize("shape", [(3, 250, 400, 32, 32), (1, 37, 70, 32, 24), (2, 8, 32, 32, 8), (5, 129, 257, 32, 16)])
 def test_conv_c32_persistent(env, shape):
     """Cin = 32, Cout <= 32 with bf16 output runs on persistent blocks (weights in registers,
     double-buffered halo, several patches per block); it accumulates the taps in the same order as
@@ -319,7 +321,8 @@ def test_conv_transpose_c64_persistent(env, shape):
             np.testing.assert_allclose(got, want, rtol=1e-2, atol=1e-2)
 
 
-@pytest.mark.parametrize("shape", [(2, 9, 21, 64, 128), (1, 20, 40, 128, 200), (1, 8, 32, 192, 64)])
+@pytest.mark.parametrize("shape", [(2, 9, 21, 64, 128), (1, 20, 40, 128, 200), (1, 8, 32, 192, 64),
+                                   (1, 13, 50, 64, 72), (3, 40, 70, 128, 512)])
 def test_conv_transpose_data_gradient(env, shape):
     """transposed = MISEG_CONV_DGRAD_T: the data gradient of Conv2DTranspose(4, 2, 'same') in one
     launch (four phase lattices of dY accumulated in the chunk loop) equals the 4x4 stride-2
