@@ -252,15 +252,17 @@ class Model:
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         t = getattr(self, "_train_state", None)
-        if t is None or t.n != batch:
+        if t is None:
             opt = self.optimizer if self.optimizer is not None else Adam()
-            new = trainer.Trainer(self.graph, self.weights, batch, device=self.device,
-                                  learning_rate=opt.learning_rate, beta_1=opt.beta_1, beta_2=opt.beta_2,
-                                  epsilon=opt.epsilon, loss=self._loss_name(), world_size=world,
-                                  freeze_encoder=self.encoder_freeze)
-            if t is not None:                       # batch size changed: carry the optimiser state over
-                new.load_state(t.state())
-            self._train_state = t = new
+            t = trainer.Trainer(self.graph, self.weights, batch, device=self.device,
+                                learning_rate=opt.learning_rate, beta_1=opt.beta_1, beta_2=opt.beta_2,
+                                epsilon=opt.epsilon, loss=self._loss_name(), world_size=world,
+                                freeze_encoder=self.encoder_freeze)
+            self._train_state = t
+        elif t.n != batch:
+            # parameters, optimiser state and BatchNorm scratch do not depend on the batch size and
+            # activations are allocated per step: a short last batch of a dataset costs nothing
+            t.set_batch(batch)
         return t
 
     @property
@@ -289,13 +291,17 @@ class Model:
             logs[getattr(m, "name", getattr(m, "__name__", str(m)))] = m.from_sums(s, pixels)
         return logs if return_dict else list(logs.values())
 
-    def sync_from_trainer(self):
+    def sync_from_trainer(self, collective=True):
         """Copy the trained parameters (and moving statistics, averaged over ranks) back into
-        `self.weights`, which inference, evaluate() and save() read."""
+        `self.weights`, which inference, evaluate() and save() read.  With `collective` (the
+        default) this is a COLLECTIVE call when torch.distributed is initialised: every rank must
+        make it (fit() does, at the end of every epoch).  collective=False only copies, and is
+        what single-rank callers such as save() use."""
         t = getattr(self, "_train_state", None)
         if t is None:
             return
-        t.average_moving_stats()
+        if collective and getattr(t, "dirty", True):
+            t.average_moving_stats()
         if getattr(t, "dirty", True):
             self.weights = t.get_weights()
             self._engines = {}
@@ -386,8 +392,13 @@ class Model:
         """`*.h5` / `*.hdf5`: a Keras HDF5 model file (keras_h5.save_keras_h5), which is what the
         reference's ModelCheckpoint writes (model_train.py:187-190,262).  Any other name: a
         single-file numpy container (.npz layout): the JSON config plus every weight under
-        '<layer>/<weight>:0'.  Both are written atomically and read back by `load_model`."""
-        self.sync_from_trainer()
+        '<layer>/<weight>:0'.  Both are written atomically and read back by `load_model`.
+
+        save() issues no collective, so one rank alone (the chief, from ModelCheckpoint) may call
+        it: fit() has already averaged the moving statistics over the ranks on every rank at the
+        end of the epoch.  Called in the middle of an epoch of a data-parallel run it writes this
+        rank's own moving statistics."""
+        self.sync_from_trainer(collective=False)
         if str(path).endswith((".h5", ".hdf5")):
             from . import keras_h5
             keras_h5.save_keras_h5(self, path)

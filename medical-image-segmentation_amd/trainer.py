@@ -940,6 +940,12 @@ class Trainer:
         self.dirty = True                 # host copies of the weights are stale
 
     # ------------------------------------------------------------------ state
+    def set_batch(self, n):
+        """Images per step from now on (nothing persistent is sized by it)."""
+        if n < 1:
+            raise ValueError("batch must be positive")
+        self.n = int(n)
+
     def state(self):
         return {"P": self.P, "M": self.M, "V": self.V, "step": self.step_count, "moving": self.moving}
 

@@ -138,6 +138,9 @@ def train(encoder, decoder, dataset, loss, learning_rate, learning_rate_factor, 
         if resume:
             model = load_model(model_path=str(Path(resume)), input_shape=input_shape, loss_function=loss_function,
                                optimizer=Adam(learning_rate=learning_rate))
+            # the checkpoint does not carry per-layer trainable flags: a run that was started with a
+            # frozen encoder stays frozen after --resume
+            model.encoder_freeze = bool(encoder_freeze)
         else:
             model = make_model(encoder, decoder, input_shape, classes, learning_rate, loss_function, metrics,
                                encoder_freeze, model_name, seed=seed)
@@ -151,6 +154,14 @@ def train(encoder, decoder, dataset, loss, learning_rate, learning_rate_factor, 
         print("\nThere was an error during training that caused it to stop: \n%s" % e)
         cfg["error"] = str(e)
         history = None
+        if distributed:
+            # the other ranks are blocked in the step's gradient all-reduce; going on to the final
+            # barrier (a different collective) would hang the job.  Record the error and leave with a
+            # failure, so that the launcher tears the whole group down.
+            if chief:
+                with open(cfg_path, "w") as f:
+                    json.dump(cfg, f, indent=4)
+            raise
     end, end_time = time.time(), time.strftime("%x %X")
     duration = get_duration(start, end)
     if "duration" in cfg:
@@ -224,12 +235,16 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
     if len(gpus) == 1 and "RANK" not in os.environ:
         os.environ.setdefault("HIP_VISIBLE_DEVICES", gpus[0])
-    train(encoder=a.encoder, decoder=a.decoder, dataset=a.dataset, loss=a.loss, learning_rate=a.lr,
+    cfg = train(encoder=a.encoder, decoder=a.decoder, dataset=a.dataset, loss=a.loss, learning_rate=a.lr,
           learning_rate_factor=a.lr_factor, classes=a.classes, epochs=a.epochs, patience=a.patience,
           batch_size=a.batch_size, steps_per_epoch=a.steps, height=a.height, width=a.width,
           augmentation=a.augmentation.lower() == "true", rgb=a.rgb, encoder_freeze=a.encoder_freeze,
           save_all=a.save_all, gpu=a.gpu, model_name=a.name, description=a.description, seed=a.seed,
           resume=a.resume, resume_epoch=a.resume_epoch)
+    if cfg.get("error"):
+        # as the reference, a failed fit() still evaluates what was saved; unlike it, the process
+        # reports the failure to its caller
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

@@ -134,3 +134,47 @@ def test_data_parallel_gradients_two_ranks_one_gpu(pkg, tmp_path):
     ref = total.cpu()
     err = float((r0["G"] - ref).norm() / ref.norm())
     assert err < 1e-3, err            # float atomics in the weight-gradient kernel reorder sums
+
+
+def _fit_ckpt_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from utils import model as um
+    from miseg_amd.callbacks import ModelCheckpoint, ReduceLROnPlateau
+    m = um.make_model("resnet18", "U-Net", (64, 64, 3), 3, 1e-3, um.CUSTOM_OBJECTS[
+        "categorical_crossentropy_plus_dice_loss"], um.METRICS, seed=1)
+    x, y = _data(8, 64, 64, seed=3)
+    xv, yv = _data(2, 64, 64, seed=9)
+    ckpt = os.path.join(out_dir, "dp_e{epoch:03d}.h5")
+    cbs = [ReduceLROnPlateau(monitor="val_f1-score", factor=0.5, min_delta=1e-3, min_lr=1e-8, patience=1, mode="max"),
+           ModelCheckpoint(ckpt, monitor="val_f1-score", mode="max", save_best_only=False)]
+    # each rank trains on its own half of the data; only the chief writes checkpoints
+    h = m.fit(_batches(x[rank::world], y[rank::world], 2), epochs=2, steps_per_epoch=2,
+              validation_data=_batches(xv, yv, 1), callbacks=cbs, verbose=0)
+    m.sync_from_trainer()                 # collective: every rank
+    flat = np.concatenate([v.ravel() for d in m.weights.values() for v in d.values()])
+    torch.save({"history": h.history, "weights": torch.from_numpy(flat)}, os.path.join(out_dir, "fit%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fit_with_checkpoint_two_ranks_stays_in_step(pkg, tmp_path):
+    """Two data-parallel ranks run fit() with a ModelCheckpoint over two epochs: the chief alone
+    saves, so saving must not issue a collective the other rank never joins (that would pair the
+    chief's all-reduce with the other rank's next gradient bucket: a hang or corrupted gradients).
+    Afterwards both ranks hold the same parameters and moving statistics and logged the same
+    epoch metrics."""
+    import torch
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_fit_ckpt_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(str(tmp_path), "fit0.pt"))
+    r1 = torch.load(os.path.join(str(tmp_path), "fit1.pt"))
+    assert torch.equal(r0["weights"], r1["weights"])
+    assert r0["history"] == r1["history"] and len(r0["history"]["val_loss"]) == 2
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.endswith(".h5"))
+    assert files == ["dp_e001.h5", "dp_e002.h5"]

@@ -57,10 +57,13 @@ def _decode(path, as_gray):
 
 
 def load_image(image_path, shape=None, normalize=False, as_gray=False, as_numpy=False,
-               return_original_shape=False):
+               return_original_shape=False, dataset_branch=False):
     """Decode one image file; optionally resize to `shape` (H, W) — nearest for files whose name
     contains "mask", bilinear otherwise — and min-max normalise.  Returns a device tensor (uint8 if
-    untouched, float32 after a bilinear resize or normalisation) or, with as_numpy, an ndarray."""
+    untouched, float32 after a bilinear resize or normalisation) or, with as_numpy, an ndarray.
+    `dataset_branch` selects the behaviour of the reference's tensor-path branch
+    (/root/reference utils/data.py:155-173), the one its tf.data training pipeline goes through:
+    every resize is nearest-neighbour, images included."""
     if isinstance(image_path, bytes):
         image_path = image_path.decode("utf-8")
     if not isinstance(image_path, (str, Path)):
@@ -75,7 +78,7 @@ def load_image(image_path, shape=None, normalize=False, as_gray=False, as_numpy=
     original_shape = tuple(raw.shape)
     image = torch.from_numpy(raw).cuda()
     if shape and tuple(shape) != tuple(raw.shape[:2]):
-        if "mask" in path.stem:
+        if dataset_branch or "mask" in path.stem:
             image = _ops.resize_nearest(image, tuple(shape), mode="tf")
         else:
             image = _ops.resize_bilinear(image, tuple(shape))
@@ -104,8 +107,8 @@ def list_files(files_path, as_numpy=False, file_types=SUPPORTED_IMAGE_TYPES, see
 
 
 def load_dataset_files(image_path, mask_path, shape, classes, mask_one_hot_encoded=True):
-    image = load_image(image_path, shape=shape, normalize=False)
-    mask = load_image(mask_path, shape=shape, as_gray=True)
+    image = load_image(image_path, shape=shape, normalize=False, dataset_branch=True)
+    mask = load_image(mask_path, shape=shape, as_gray=True, dataset_branch=True)
     if mask_one_hot_encoded:
         mask = one_hot_encode(mask, classes=classes)
     return image, mask

@@ -57,8 +57,10 @@ def evaluate(models_paths, images_path, batch_size=1, classes=3, one_hot_encoded
         raise FileNotFoundError("No file models were found at `%s`." % models_paths)
     if not paths:
         return None, None
+    # the whole test set on the calling process, also when torch.distributed is initialised (the
+    # training script evaluates on its chief rank only): no per-rank split here
     dataset = load_dataset(images_path, batch_size=batch_size, shape=input_shape[:2], classes=classes,
-                           mask_one_hot_encoded=one_hot_encoded, shuffle=False)
+                           mask_one_hot_encoded=one_hot_encoded, shuffle=False, rank=0, world=1)
     parent = Path(paths[0]).parent
     cfg = parent.joinpath("train_config_%s.json" % parent.name)
     if cfg.is_file():

@@ -19,10 +19,34 @@ from miseg_amd import imageops as _ops, shard as _shard
 from miseg_amd.model import Model as _Model
 
 
-def patch_predict(model, image, patch_shape):
-    """Forward `image` (H,W,3 float32, host or device) in non-overlapping patches of the model's
-    input size; the last patch of each axis is shifted back to end at the border.  Returns the
-    (H,W,classes) float32 probabilities as a device tensor."""
+def halo_ranges(size, patch, halo):
+    """Windows of `patch` pixels along one axis of `size` pixels whose inner parts tile the axis:
+    a list of (window start, paste from, paste to).  A window gives up `halo` pixels at every edge
+    that is not the image border, so each output pixel comes from a window that saw at least `halo`
+    pixels of context on every side (or the image border).  The last window is shifted back to end
+    at the border, as the reference's tiles are (/root/reference utils/predict.py:47-61)."""
+    if halo < 0 or 2 * halo >= patch:
+        raise ValueError("halo must satisfy 0 <= 2 * halo < patch (%d), got %d" % (patch, halo))
+    if size < patch:
+        raise ValueError("the image (%d) is smaller than the patch (%d)" % (size, patch))
+    out, lo = [], 0
+    while lo < size:
+        start = min(max(lo - halo, 0), size - patch)
+        hi = size if start + patch >= size else start + patch - halo
+        out.append((start, lo, hi))
+        lo = hi
+    return out
+
+
+def patch_predict(model, image, patch_shape, halo=0):
+    """Forward `image` (H,W,3 float32, host or device) in patches of the model's input size.
+    Returns the (H,W,classes) float32 probabilities as a device tensor.
+
+    halo = 0 (default) is the reference's `patch_predict`: non-overlapping patches, the last patch
+    of each axis shifted back to end at the border, later patches overwriting earlier ones where
+    they overlap; every patch is forwarded without context, so predictions change at patch seams.
+    halo > 0 (an option the reference does not have) forwards overlapping windows and keeps only
+    the part of each that lies at least `halo` pixels inside it (see `halo_ranges`)."""
     input_shape = get_model_input_shape(model)
     if tuple(input_shape) != tuple(patch_shape):
         raise ValueError("The model's input shape does not match the patch shape: model '%s' != patch '%s'."
@@ -32,6 +56,15 @@ def patch_predict(model, image, patch_shape):
     image = image.cuda()
     h, w = image.shape[:2]
     out = None
+    if halo:
+        for ys, y0, y1 in halo_ranges(h, patch_shape[0], halo):
+            for xs, x0, x1 in halo_ranges(w, patch_shape[1], halo):
+                window = image[ys:ys + patch_shape[0], xs:xs + patch_shape[1]]
+                pr = model(window.unsqueeze(0).contiguous(), training=False).tensor[0]
+                if out is None:
+                    out = torch.zeros((h, w, pr.shape[-1]), dtype=torch.float32, device=pr.device)
+                out[y0:y1, x0:x1] = pr[y0 - ys:y1 - ys, x0 - xs:x1 - xs]
+        return out
     for y0, y1 in _shard.tile_ranges(h, patch_shape[0]):
         for x0, x1 in _shard.tile_ranges(w, patch_shape[1]):
             pr = model(image[y0:y1, x0:x1].unsqueeze(0).contiguous(), training=False).tensor[0]
