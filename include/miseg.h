@@ -264,6 +264,20 @@ int miseg_bn_stats_fwd(const void* x, int64_t pixels, int32_t C, int32_t pix_str
                        const float* gamma, const float* beta, float* moving_mean,
                        float* moving_var, float momentum, float eps, float* mean, float* var,
                        float* scale, float* shift, double* workspace, void* stream);
+/*
+ * miseg_bn_stats_fwd without the workspace argument and without any allocation.  It has no
+ * counterpart in the reference: it exists for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  The double[2*C]
+ * partial sums live in a 64 KB array built into the library (one copy per GPU, held until the
+ * process ends), so C <= 4096: larger C is rejected with MISEG_E_INVALID_ARG.  Every call on a GPU
+ * shares that GPU's array: two calls that overlap on one GPU (different streams or threads) race;
+ * calls on one stream are safe.  The first call on a device looks the array's address up
+ * (miseg_device_check does it too: call that once per device before capturing a graph).
+ */
+int miseg_bn_stats_fwd_noalloc(const void* x, int64_t pixels, int32_t C, int32_t pix_stride,
+                               const float* gamma, const float* beta, float* moving_mean,
+                               float* moving_var, float momentum, float eps, float* mean, float* var,
+                               float* scale, float* shift, void* stream);
 /* The same for the fp32 3-channel network input (ResNet `bn_data`, scale=False). */
 int miseg_input_stats_fwd(const float* x, int64_t pixels, const float* beta, float* moving_mean,
                           float* moving_var, float momentum, float eps, float* mean, float* var,

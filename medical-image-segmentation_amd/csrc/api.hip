@@ -38,6 +38,9 @@ int launch_bn_finalize(const double*, int, int, long long, int, const float*, co
                        float, float, float*, float*, float*, float*, hipStream_t);
 int launch_bn_stats(const void*, long long, int, int, const float*, const float*, float*, float*, float,
                     float, float*, float*, float*, float*, double*, hipStream_t);
+int launch_bn_stats_noalloc(const void*, long long, int, int, const float*, const float*, float*, float*,
+                            float, float, float*, float*, float*, float*, hipStream_t);
+int noalloc_setup(double** out);
 int launch_input_stats(const float*, long long, const float*, float*, float*, float, float, float*,
                        float*, float*, float*, double*, hipStream_t);
 int launch_bn_relu_bwd_reduce(const void*, const void*, long long, int, int, int, const float*,
@@ -132,7 +135,9 @@ int miseg_device_check(void) {
     set_error("device %d is %s, this library is built for gfx950 only", dev, prop.gcnArchName);
     return MISEG_E_NO_DEVICE;
   }
-  return MISEG_OK;
+  // set-up of the allocation-free entry point: look up this device's scratch array now, so that
+  // miseg_bn_stats_fwd_noalloc makes no runtime query later (e.g. under stream capture)
+  return noalloc_setup(nullptr);
 }
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream) {
@@ -207,6 +212,12 @@ int miseg_bn_stats_fwd(const void* x, int64_t pixels, int32_t C, int32_t ps, con
                        float* mean, float* var, float* scale, float* shift, double* ws, void* stream) {
   return launch_bn_stats(x, pixels, C, ps, gamma, beta, mm, mv, momentum, eps, mean, var, scale,
                          shift, ws, (hipStream_t)stream);
+}
+int miseg_bn_stats_fwd_noalloc(const void* x, int64_t pixels, int32_t C, int32_t ps, const float* gamma,
+                               const float* beta, float* mm, float* mv, float momentum, float eps,
+                               float* mean, float* var, float* scale, float* shift, void* stream) {
+  return launch_bn_stats_noalloc(x, pixels, C, ps, gamma, beta, mm, mv, momentum, eps, mean, var, scale,
+                                 shift, (hipStream_t)stream);
 }
 int miseg_input_stats_fwd(const float* x, int64_t pixels, const float* beta, float* mm, float* mv,
                           float momentum, float eps, float* mean, float* var, float* scale,

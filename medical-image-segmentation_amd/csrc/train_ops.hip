@@ -174,6 +174,45 @@ int launch_bn_stats(const void* x, long long pixels, int C, int ps, const float*
   return MISEG_OK;
 }
 
+// ---- the same without a workspace argument: the double[2*C] partial sums live in a file-scope
+// device array, for callers that cannot allocate (HIP graph capture, serving loops).  Each GPU
+// holds its own copy of the array at its own address; g_bn_scratch_ptr[dev] is that address,
+// looked up once per device.  In host code `g_bn_scratch` itself is only a handle for
+// hipGetSymbolAddress, never a device address.
+constexpr int kNoAllocMaxC = 4096;
+constexpr int kNoAllocMaxDevices = 64;
+static __device__ __align__(256) double g_bn_scratch[2 * kNoAllocMaxC];   // 64 KB per GPU
+static double* g_bn_scratch_ptr[kNoAllocMaxDevices] = {};
+
+// Address of this device's scratch array (looked up on the first call per device; idempotent, and a
+// race between two first calls stores the same value twice).
+int noalloc_setup(double** out) {
+  int dev = -1;
+  MISEG_CHECK_HIP(hipGetDevice(&dev));
+  MISEG_CHECK_ARG(dev >= 0 && dev < kNoAllocMaxDevices, "no-alloc scratch: device index %d out of range", dev);
+  double* ptr = __atomic_load_n(&g_bn_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!ptr) {
+    MISEG_CHECK_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(g_bn_scratch)));
+    MISEG_CHECK_ARG(ptr != nullptr, "no-alloc scratch: hipGetSymbolAddress returned a null address");
+    __atomic_store_n(&g_bn_scratch_ptr[dev], ptr, __ATOMIC_RELEASE);
+  }
+  if (out) *out = ptr;
+  return MISEG_OK;
+}
+
+int launch_bn_stats_noalloc(const void* x, long long pixels, int C, int ps, const float* gamma,
+                            const float* beta, float* mm, float* mv, float momentum, float eps,
+                            float* mean, float* var, float* scale, float* shift, hipStream_t s) {
+  MISEG_CHECK_ARG(C > 0 && C <= kNoAllocMaxC,
+                  "bn_stats_noalloc: C = %d exceeds the built-in scratch (at most %d channels)", C, kNoAllocMaxC);
+  double* ws = nullptr;
+  const int rc = noalloc_setup(&ws);
+  if (rc != MISEG_OK) return rc;
+  // launch_bn_stats clears ws[0, 2*C) on the stream before the reduction, so whatever the previous
+  // call left behind (possibly for more channels) does not show
+  return launch_bn_stats(x, pixels, C, ps, gamma, beta, mm, mv, momentum, eps, mean, var, scale, shift, ws, s);
+}
+
 // fp32 3-channel network input
 __global__ void input_stats_kernel(const float* __restrict__ x, long long pixels,
                                    double* __restrict__ sums) {

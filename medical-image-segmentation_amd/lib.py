@@ -77,6 +77,8 @@ SIGNATURES = {
     "miseg_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), _VP]),
     "miseg_bn_stats_fwd": (C.c_int, [_VP, _I64, _I32, _I32, _FP, _FP, _FP, _FP, C.c_float, C.c_float,
                                      _FP, _FP, _FP, _FP, _VP, _VP]),
+    "miseg_bn_stats_fwd_noalloc": (C.c_int, [_VP, _I64, _I32, _I32, _FP, _FP, _FP, _FP, C.c_float, C.c_float,
+                                             _FP, _FP, _FP, _FP, _VP]),
     "miseg_bn_finalize": (C.c_int, [_VP, _I32, _I32, _I64, _I32, _FP, _FP, _FP, _FP, C.c_float, C.c_float,
                                     _FP, _FP, _FP, _FP, _VP]),
     "miseg_input_stats_fwd": (C.c_int, [_FP, _I64, _FP, _FP, _FP, C.c_float, C.c_float, _FP, _FP, _FP,
