@@ -33,8 +33,19 @@ extern "C" {
 #define MISEG_E_HIP (-3)
 #define MISEG_E_NO_DEVICE (-4)
 
-#define MISEG_DT_BF16 0
+#define MISEG_DT_BF16 0 /* the call's 16-bit storage format: bf16, or fp16 when fmt = MISEG_FMT_F16 */
 #define MISEG_DT_F32 1
+
+/*
+ * 16-bit storage format of activations and convolution weights.  The training path and the
+ * default of every entry point is bf16.  The inference kernels exist a second time for IEEE
+ * fp16 (same kernels, same matrix-instruction rate, same bytes; values saturate at +-65504):
+ * 11 significand bits instead of 8, which is what it takes for the strict-argmax masks of
+ * utils/utils.py:50-68 to agree with an fp32 run of model(batch, training=False)
+ * (utils/predict.py:159) on >= 99.9 % of the pixels.  fp32 accumulation in both.
+ */
+#define MISEG_FMT_BF16 0
+#define MISEG_FMT_F16 1
 
 /* epilogue of the main output */
 #define MISEG_ACT_NONE 0
@@ -128,6 +139,8 @@ typedef struct miseg_conv_desc {
   void* stats;
   int32_t stats_replicas;
   int32_t stats_stride;
+  int32_t fmt;   /* MISEG_FMT_*: format of in, weight, out2 and of out / residual where their dtype is
+                    MISEG_DT_BF16 (read: "16-bit"). */
 } miseg_conv_desc;
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);
@@ -192,6 +205,27 @@ int miseg_upsample_bilinear2x_fwd(const void* in, void* out, int32_t N, int32_t 
 int miseg_scale_shift_relu_fwd(const void* in, void* out, const float* scale, const float* shift,
                                int64_t pixels, int32_t C, int32_t in_pix_stride,
                                int32_t out_pix_stride, void* stream);
+
+/*
+ * The six layers above on fp16 storage (MISEG_FMT_F16); same arguments.  Inference only.
+ */
+int miseg_prep_input_f16(const float* in, void* out, const float* scale, const float* shift,
+                         int32_t N, int32_t H, int32_t W, void* stream);
+int miseg_maxpool3x3s2_fwd_f16(const void* in, void* out, const float* scale, const float* shift,
+                               int32_t N, int32_t H, int32_t W, int32_t C,
+                               int32_t in_pix_stride, int32_t out_pix_stride, void* stream);
+int miseg_avgpool2x2_fwd_f16(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                             int32_t in_pix_stride, int32_t out_pix_stride, void* stream);
+int miseg_upsample_nearest_fwd_f16(const void* in, const void* addend, void* out,
+                                   int32_t N, int32_t H, int32_t W, int32_t C, int32_t shift,
+                                   int32_t in_pix_stride, int32_t add_pix_stride,
+                                   int32_t out_pix_stride, void* stream);
+int miseg_upsample_bilinear2x_fwd_f16(const void* in, void* out, int32_t N, int32_t H, int32_t W,
+                                      int32_t C, int32_t in_pix_stride, int32_t out_pix_stride,
+                                      void* stream);
+int miseg_scale_shift_relu_fwd_f16(const void* in, void* out, const float* scale, const float* shift,
+                                   int64_t pixels, int32_t C, int32_t in_pix_stride,
+                                   int32_t out_pix_stride, void* stream);
 
 /*
  * collapse_probabilities (utils/utils.py:50-68) on device: fp32 probabilities
@@ -413,6 +447,9 @@ typedef struct miseg_plan miseg_plan;
 miseg_plan* miseg_plan_create(void);
 void miseg_plan_destroy(miseg_plan* p);
 int miseg_plan_num_ops(const miseg_plan* p);
+/* Storage format (MISEG_FMT_*) of every op of the plan; call before the first miseg_plan_add_*.
+ * Convolution descriptors added afterwards must carry the same `fmt`. */
+int miseg_plan_set_format(miseg_plan* p, int32_t fmt);
 int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d);
 int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, const miseg_conv_desc* head);
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,

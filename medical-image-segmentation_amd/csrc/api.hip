@@ -17,20 +17,7 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-int launch_conv(const miseg_conv_desc* d, hipStream_t stream);
-int validate_conv(const miseg_conv_desc* d);
-void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len);
-int validate_conv_c32_head(const miseg_conv_desc* body, const miseg_conv_desc* head);
-int launch_conv_c32_head(const miseg_conv_desc* body, const miseg_conv_desc* head, hipStream_t stream);
-int launch_prep_input(const float*, void*, const float*, const float*, int, int, int, hipStream_t, bool indicator = false);
-int launch_maxpool3x3s2(const void*, void*, const float*, const float*, int, int, int, int, int,
-                        int, hipStream_t);
-int launch_avgpool2x2(const void*, void*, int, int, int, int, int, int, hipStream_t);
-int launch_upsample_nearest(const void*, const void*, void*, int, int, int, int, int, int, int,
-                            int, hipStream_t);
-int launch_upsample_bilinear2x(const void*, void*, int, int, int, int, int, int, hipStream_t);
-int launch_scale_shift_relu(const void*, void*, const float*, const float*, long long, int, int,
-                            int, hipStream_t);
+#include "inference_decls.inc"
 int launch_collapse_u8(const float*, uint8_t*, long long, int, int, hipStream_t);
 int launch_loss_sums(const float*, const float*, double*, long long, int, hipStream_t);
 int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream);
@@ -72,6 +59,12 @@ int launch_loss_sums_focal(const float*, const float*, double*, long long, int, 
 int launch_adam(float*, float*, float*, const float*, void*, long long, float, float, float, float,
                 float, hipStream_t);
 
+}  // namespace miseg
+namespace miseg_f16 {
+#include "inference_decls.inc"
+}
+namespace miseg {
+
 enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD };
 
 struct Op {
@@ -87,7 +80,28 @@ struct Op {
   int N, H, W, C, shift_bits, ips, aps, ops;
 };
 
-static int run_op(const Op& o, hipStream_t s) {
+static int run_op_f16(const Op& o, hipStream_t s) {
+  namespace F = ::miseg_f16;
+  switch (o.kind) {
+    case OP_CONV: return F::launch_conv(&o.conv, s);
+    case OP_CONV_HEAD: return F::launch_conv_c32_head(&o.conv, &o.conv2, s);
+    case OP_PREP: return F::launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
+    case OP_MAXPOOL:
+      return F::launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_AVGPOOL: return F::launch_avgpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_UPNEAR:
+      return F::launch_upsample_nearest(o.in, o.in2, o.out, o.N, o.H, o.W, o.C, o.shift_bits, o.ips,
+                                        o.aps, o.ops, s);
+    case OP_UPBIL: return F::launch_upsample_bilinear2x(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_SSR:
+      return F::launch_scale_shift_relu(o.in, o.out, o.scale, o.shift, o.pixels, o.C, o.ips, o.ops, s);
+  }
+  set_error("plan: unknown op kind");
+  return MISEG_E_INVALID_ARG;
+}
+
+static int run_op(const Op& o, hipStream_t s, int fmt) {
+  if (fmt == MISEG_FMT_F16) return run_op_f16(o, s);
   switch (o.kind) {
     case OP_CONV: return launch_conv(&o.conv, s);
     case OP_CONV_HEAD: return launch_conv_c32_head(&o.conv, &o.conv2, s);
@@ -110,7 +124,10 @@ static int run_op(const Op& o, hipStream_t s) {
 
 struct miseg_plan {
   std::vector<miseg::Op> ops;
+  int fmt = MISEG_FMT_BF16;
 };
+
+#define MISEG_CHECK_FMT(fmt) MISEG_CHECK_ARG((fmt) == MISEG_FMT_BF16 || (fmt) == MISEG_FMT_F16, "unknown storage format %d", (int)(fmt))
 
 using namespace miseg;
 
@@ -141,11 +158,47 @@ int miseg_device_check(void) {
 }
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream) {
+  MISEG_CHECK_ARG(d, "conv: null descriptor");
+  MISEG_CHECK_FMT(d->fmt);
+  if (d->fmt == MISEG_FMT_F16) return miseg_f16::launch_conv(d, (hipStream_t)stream);
   return launch_conv(d, (hipStream_t)stream);
 }
 
 int miseg_conv_c32_head_fwd(const miseg_conv_desc* body, const miseg_conv_desc* head, void* stream) {
+  MISEG_CHECK_ARG(body && head, "conv_c32_head: null descriptor");
+  MISEG_CHECK_FMT(body->fmt);
+  MISEG_CHECK_ARG(body->fmt == head->fmt, "conv_c32_head: body and head must use one storage format");
+  if (body->fmt == MISEG_FMT_F16) return miseg_f16::launch_conv_c32_head(body, head, (hipStream_t)stream);
   return launch_conv_c32_head(body, head, (hipStream_t)stream);
+}
+
+// fp16-storage twins of the layers between the convolutions (inference only)
+int miseg_prep_input_f16(const float* in, void* out, const float* scale, const float* shift, int32_t N,
+                         int32_t H, int32_t W, void* stream) {
+  return miseg_f16::launch_prep_input(in, out, scale, shift, N, H, W, (hipStream_t)stream);
+}
+int miseg_maxpool3x3s2_fwd_f16(const void* in, void* out, const float* scale, const float* shift,
+                               int32_t N, int32_t H, int32_t W, int32_t C, int32_t ips, int32_t ops,
+                               void* stream) {
+  return miseg_f16::launch_maxpool3x3s2(in, out, scale, shift, N, H, W, C, ips, ops, (hipStream_t)stream);
+}
+int miseg_avgpool2x2_fwd_f16(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                             int32_t ips, int32_t ops, void* stream) {
+  return miseg_f16::launch_avgpool2x2(in, out, N, H, W, C, ips, ops, (hipStream_t)stream);
+}
+int miseg_upsample_nearest_fwd_f16(const void* in, const void* addend, void* out, int32_t N, int32_t H,
+                                   int32_t W, int32_t C, int32_t shift, int32_t ips, int32_t aps,
+                                   int32_t ops, void* stream) {
+  return miseg_f16::launch_upsample_nearest(in, addend, out, N, H, W, C, shift, ips, aps, ops,
+                                            (hipStream_t)stream);
+}
+int miseg_upsample_bilinear2x_fwd_f16(const void* in, void* out, int32_t N, int32_t H, int32_t W,
+                                      int32_t C, int32_t ips, int32_t ops, void* stream) {
+  return miseg_f16::launch_upsample_bilinear2x(in, out, N, H, W, C, ips, ops, (hipStream_t)stream);
+}
+int miseg_scale_shift_relu_fwd_f16(const void* in, void* out, const float* scale, const float* shift,
+                                   int64_t pixels, int32_t C, int32_t ips, int32_t ops, void* stream) {
+  return miseg_f16::launch_scale_shift_relu(in, out, scale, shift, pixels, C, ips, ops, (hipStream_t)stream);
 }
 
 int miseg_prep_input(const float* in, void* out, const float* scale, const float* shift, int32_t N,
@@ -315,8 +368,18 @@ miseg_plan* miseg_plan_create(void) { return new miseg_plan(); }
 void miseg_plan_destroy(miseg_plan* p) { delete p; }
 int miseg_plan_num_ops(const miseg_plan* p) { return p ? (int)p->ops.size() : 0; }
 
-int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d) {
+int miseg_plan_set_format(miseg_plan* p, int32_t fmt) {
   MISEG_CHECK_ARG(p, "plan: null plan");
+  MISEG_CHECK_FMT(fmt);
+  MISEG_CHECK_ARG(p->ops.empty(), "plan: the storage format must be chosen before the first op is added");
+  p->fmt = fmt;
+  return MISEG_OK;
+}
+
+int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d) {
+  MISEG_CHECK_ARG(p && d, "plan: null argument");
+  MISEG_CHECK_ARG(d->fmt == p->fmt, "plan: the convolution's storage format (%d) differs from the plan's (%d)",
+                  (int)d->fmt, p->fmt);
   int rc = validate_conv(d);
   if (rc != MISEG_OK) return rc;
   Op o{};
@@ -327,7 +390,9 @@ int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d) {
 }
 
 int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, const miseg_conv_desc* head) {
-  MISEG_CHECK_ARG(p, "plan: null plan");
+  MISEG_CHECK_ARG(p && body && head, "plan: null argument");
+  MISEG_CHECK_ARG(body->fmt == p->fmt && head->fmt == p->fmt,
+                  "plan: the convolutions' storage format differs from the plan's (%d)", p->fmt);
   int rc = validate_conv_c32_head(body, head);
   if (rc != MISEG_OK) return rc;
   Op o{};
@@ -412,7 +477,7 @@ int miseg_plan_run_range(const miseg_plan* p, int first, int last, void* stream,
     MISEG_CHECK_HIP(hipEventRecord(e0, s));
   }
   int rc = MISEG_OK;
-  for (int i = first; i < last && rc == MISEG_OK; ++i) rc = run_op(p->ops[i], s);
+  for (int i = first; i < last && rc == MISEG_OK; ++i) rc = run_op(p->ops[i], s, p->fmt);
   if (ms) {
     hipError_t e = hipEventRecord(e1, s);
     if (e == hipSuccess) e = hipEventSynchronize(e1);

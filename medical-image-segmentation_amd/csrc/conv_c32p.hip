@@ -16,7 +16,7 @@
 //    are flushed once.
 #include "conv_common.h"
 
-namespace miseg {
+namespace MISEG_KNS {
 
 namespace {
 constexpr int CP_TH = 8, CP_TW = 32, CP_HWD = CP_TW + 2;
@@ -55,11 +55,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
 
   // ---- weights: fragment [tap][kk] = cout lrow, k = kk * 16 + lhalf * 8 .. + 7 (rows past Cout
   //      repeat row 0: their results are never stored) ----
-  bf16x8 wreg[9][2];
+  h16x8 wreg[9][2];
   static_for<18>([&](auto ic) __attribute__((always_inline)) {
     constexpr int tap = decltype(ic)::value >> 1, kk = decltype(ic)::value & 1;
-    const bf16_t* wsrc = p.weight + ((lrow < p.Cout ? lrow : 0) * 9 + tap) * 32 + kk * 16 + lhalf * 8;
-    wreg[tap][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wsrc));
+    const h16_t* wsrc = p.weight + ((lrow < p.Cout ? lrow : 0) * 9 + tap) * 32 + kk * 16 + lhalf * 8;
+    wreg[tap][kk] = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(wsrc));
   });
   // ---- epilogue coefficients wait in LDS between patches ----
   float* coef = reinterpret_cast<float*>(lds + 2 * CP_HALO_BYTES);
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-    bf16x8 xf[2][6];   // [halo row parity][dx * 2 + kk]
-    auto read_row = [&](auto rc, bf16x8 (&x)[6]) __attribute__((always_inline)) {
+    h16x8 xf[2][6];   // [halo row parity][dx * 2 + kk]
+    auto read_row = [&](auto rc, h16x8 (&x)[6]) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value;
       static_for<6>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
@@ -171,9 +171,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
         constexpr int i = decltype(ic)::value;
         constexpr int dx = i >> 1, kk = i & 1;
         if constexpr (r < 3)
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[r * 3 + dx][kk], xf[r & 1][i], acc[0], 0, 0, 0);
+          acc[0] = mfma_32x32x16(wreg[r * 3 + dx][kk], xf[r & 1][i], acc[0]);
         if constexpr (r >= 1)
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[(r - 1) * 3 + dx][kk], xf[r & 1][i], acc[1], 0, 0, 0);
+          acc[1] = mfma_32x32x16(wreg[(r - 1) * 3 + dx][kk], xf[r & 1][i], acc[1]);
       });
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (r + 2 < 4) read_row(std::integral_constant<int, r + 2>{}, xf[r & 1]);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CP_TICK(3);
     {
-      bf16x8 c[8];
+      h16x8 c[8];
       ds_read_b128_at<0>(c[0], coef_a);
       ds_read_b128_at<16>(c[1], coef_a);
       ds_read_b128_at<64>(c[2], coef_a);
@@ -271,4 +271,4 @@ hipError_t launch_conv_c32p(const ConvParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-}  // namespace miseg
+}  // namespace MISEG_KNS

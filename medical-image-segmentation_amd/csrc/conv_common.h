@@ -6,7 +6,7 @@
 
 #include "common.h"
 
-namespace miseg {
+namespace MISEG_KNS {
 
 // Compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>).  Keeps
 // accumulator arrays indexed by constants only (a runtime index would move them to scratch).
@@ -19,14 +19,13 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef f32x16_t f32x16;
 
 struct ConvParams {
-  const bf16_t* in;
-  const bf16_t* weight;
+  const h16_t* in;
+  const h16_t* weight;
   void* out;
-  bf16_t* out2;
+  h16_t* out2;
   const void* residual;
   const float* scale;
   const float* shift;
@@ -74,7 +73,7 @@ __device__ __forceinline__ int swz128(int row, int chunk) {
 
 struct TileCoord {
   int m0, cout0, ph_a, ph_b, pad_y, pad_x;
-  const bf16_t* wbase;
+  const h16_t* wbase;
 };
 
 // PHASES = false: a transpose-conv kernel that computes all four phases of a tile in one block
@@ -280,11 +279,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
             v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
           } else {
             const uint4 r = *reinterpret_cast<const uint4*>(
-                reinterpret_cast<const bf16_t*>(p.residual) + r_off);
-            v[0] += bf16lo_to_f32(r.x); v[1] += bf16hi_to_f32(r.x);
-            v[2] += bf16lo_to_f32(r.y); v[3] += bf16hi_to_f32(r.y);
-            v[4] += bf16lo_to_f32(r.z); v[5] += bf16hi_to_f32(r.z);
-            v[6] += bf16lo_to_f32(r.w); v[7] += bf16hi_to_f32(r.w);
+                reinterpret_cast<const h16_t*>(p.residual) + r_off);
+            v[0] += h16lo_to_f32(r.x); v[1] += h16hi_to_f32(r.x);
+            v[2] += h16lo_to_f32(r.y); v[3] += h16hi_to_f32(r.y);
+            v[4] += h16lo_to_f32(r.z); v[5] += h16hi_to_f32(r.z);
+            v[6] += h16lo_to_f32(r.w); v[7] += h16hi_to_f32(r.w);
           }
         }
         if (p.out) {
@@ -296,13 +295,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
             *reinterpret_cast<float4*>(o) = make_float4(w[0], w[1], w[2], w[3]);
             *reinterpret_cast<float4*>(o + 4) = make_float4(w[4], w[5], w[6], w[7]);
           } else {
-            const uint4 pk = make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]),
-                                        pack_bf16x2(w[4], w[5]), pack_bf16x2(w[6], w[7]));
-            *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o_off) = pk;
+            float u[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] = h16_act(v[j], p.act == MISEG_ACT_RELU);
+            const uint4 pk = make_uint4(pack_h16x2_raw(u[0], u[1]), pack_h16x2_raw(u[2], u[3]),
+                                        pack_h16x2_raw(u[4], u[5]), pack_h16x2_raw(u[6], u[7]));
+            *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + o_off) = pk;
             if (p.stats) {
-              const float r[8] = {bf16lo_to_f32(pk.x), bf16hi_to_f32(pk.x), bf16lo_to_f32(pk.y),
-                                  bf16hi_to_f32(pk.y), bf16lo_to_f32(pk.z), bf16hi_to_f32(pk.z),
-                                  bf16lo_to_f32(pk.w), bf16hi_to_f32(pk.w)};
+              const float r[8] = {h16lo_to_f32(pk.x), h16hi_to_f32(pk.x), h16lo_to_f32(pk.y),
+                                  h16hi_to_f32(pk.y), h16lo_to_f32(pk.z), h16hi_to_f32(pk.z),
+                                  h16lo_to_f32(pk.w), h16hi_to_f32(pk.w)};
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
                 st_s[j] += r[j];
@@ -317,10 +319,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
           const float4 t0 = *reinterpret_cast<const float4*>(p.shift2 + cox);
           const float4 t1 = *reinterpret_cast<const float4*>(p.shift2 + cox + 4);
           *reinterpret_cast<uint4*>(p.out2 + o2_off) = make_uint4(
-              pack_bf16x2(fmaxf(v[0] * s0.x + t0.x, 0.f), fmaxf(v[1] * s0.y + t0.y, 0.f)),
-              pack_bf16x2(fmaxf(v[2] * s0.z + t0.z, 0.f), fmaxf(v[3] * s0.w + t0.w, 0.f)),
-              pack_bf16x2(fmaxf(v[4] * s1.x + t1.x, 0.f), fmaxf(v[5] * s1.y + t1.y, 0.f)),
-              pack_bf16x2(fmaxf(v[6] * s1.z + t1.z, 0.f), fmaxf(v[7] * s1.w + t1.w, 0.f)));
+              pack_h16x2_raw(h16_relu(v[0] * s0.x + t0.x), h16_relu(v[1] * s0.y + t0.y)),
+              pack_h16x2_raw(h16_relu(v[2] * s0.z + t0.z), h16_relu(v[3] * s0.w + t0.w)),
+              pack_h16x2_raw(h16_relu(v[4] * s1.x + t1.x), h16_relu(v[5] * s1.y + t1.y)),
+              pack_h16x2_raw(h16_relu(v[6] * s1.z + t1.z), h16_relu(v[7] * s1.w + t1.w)));
         }
         continue;
       }
@@ -333,7 +335,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
           if (has_res)
             v[j] += p.res_dtype == MISEG_DT_F32
                         ? reinterpret_cast<const float*>(p.residual)[r_off + j]
-                        : bf16_to_f32(reinterpret_cast<const bf16_t*>(p.residual)[r_off + j]);
+                        : h16_to_f32(reinterpret_cast<const h16_t*>(p.residual)[r_off + j]);
         }
       }
       if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID) {
@@ -350,10 +352,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
           if (p.out_dtype == MISEG_DT_F32)
             reinterpret_cast<float*>(p.out)[o_off + j] = w;
           else
-            reinterpret_cast<bf16_t*>(p.out)[o_off + j] = f32_to_bf16(w);
+            reinterpret_cast<h16_t*>(p.out)[o_off + j] = f32_to_h16(w);
         }
         if (p.out2)
-          p.out2[o2_off + j] = f32_to_bf16(fmaxf(v[j] * p.scale2[cox + j] + p.shift2[cox + j], 0.f));
+          p.out2[o2_off + j] = f32_to_h16(fmaxf(v[j] * p.scale2[cox + j] + p.shift2[cox + j], 0.f));
       }
     }
   });
@@ -477,10 +479,10 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const uint4 r = res[q];
-      v[8 * q + 0] += bf16lo_to_f32(r.x); v[8 * q + 1] += bf16hi_to_f32(r.x);
-      v[8 * q + 2] += bf16lo_to_f32(r.y); v[8 * q + 3] += bf16hi_to_f32(r.y);
-      v[8 * q + 4] += bf16lo_to_f32(r.z); v[8 * q + 5] += bf16hi_to_f32(r.z);
-      v[8 * q + 6] += bf16lo_to_f32(r.w); v[8 * q + 7] += bf16hi_to_f32(r.w);
+      v[8 * q + 0] += h16lo_to_f32(r.x); v[8 * q + 1] += h16hi_to_f32(r.x);
+      v[8 * q + 2] += h16lo_to_f32(r.y); v[8 * q + 3] += h16hi_to_f32(r.y);
+      v[8 * q + 4] += h16lo_to_f32(r.z); v[8 * q + 5] += h16hi_to_f32(r.z);
+      v[8 * q + 6] += h16lo_to_f32(r.w); v[8 * q + 7] += h16hi_to_f32(r.w);
     }
   }
 #pragma unroll
@@ -489,13 +491,13 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
     const float* w = v + 8 * q;
     float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = d.relu ? fmaxf(w[j], 0.f) : w[j];
-    const uint4 pk = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
-                                pack_bf16x2(o[6], o[7]));
-    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.out) + o_off + d.c2[q]) = pk;
+    for (int j = 0; j < 8; ++j) o[j] = h16_act(w[j], d.relu);
+    const uint4 pk = make_uint4(pack_h16x2_raw(o[0], o[1]), pack_h16x2_raw(o[2], o[3]), pack_h16x2_raw(o[4], o[5]),
+                                pack_h16x2_raw(o[6], o[7]));
+    *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + o_off + d.c2[q]) = pk;
     if (do_stats) {
-      const float r[8] = {bf16lo_to_f32(pk.x), bf16hi_to_f32(pk.x), bf16lo_to_f32(pk.y), bf16hi_to_f32(pk.y),
-                          bf16lo_to_f32(pk.z), bf16hi_to_f32(pk.z), bf16lo_to_f32(pk.w), bf16hi_to_f32(pk.w)};
+      const float r[8] = {h16lo_to_f32(pk.x), h16hi_to_f32(pk.x), h16lo_to_f32(pk.y), h16hi_to_f32(pk.y),
+                          h16lo_to_f32(pk.z), h16hi_to_f32(pk.z), h16lo_to_f32(pk.w), h16hi_to_f32(pk.w)};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         st[8 * q + j] += r[j];
@@ -506,10 +508,10 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
       const float* s = d2->s2 + 8 * q;
       const float* t = d2->t2 + 8 * q;
       *reinterpret_cast<uint4*>(p.out2 + o2_off + d.c2[q]) = make_uint4(
-          pack_bf16x2(fmaxf(w[0] * s[0] + t[0], 0.f), fmaxf(w[1] * s[1] + t[1], 0.f)),
-          pack_bf16x2(fmaxf(w[2] * s[2] + t[2], 0.f), fmaxf(w[3] * s[3] + t[3], 0.f)),
-          pack_bf16x2(fmaxf(w[4] * s[4] + t[4], 0.f), fmaxf(w[5] * s[5] + t[5], 0.f)),
-          pack_bf16x2(fmaxf(w[6] * s[6] + t[6], 0.f), fmaxf(w[7] * s[7] + t[7], 0.f)));
+          pack_h16x2_raw(h16_relu(w[0] * s[0] + t[0]), h16_relu(w[1] * s[1] + t[1])),
+          pack_h16x2_raw(h16_relu(w[2] * s[2] + t[2]), h16_relu(w[3] * s[3] + t[3])),
+          pack_h16x2_raw(h16_relu(w[4] * s[4] + t[4]), h16_relu(w[5] * s[5] + t[5])),
+          pack_h16x2_raw(h16_relu(w[6] * s[6] + t[6]), h16_relu(w[7] * s[7] + t[7])));
     }
   }
 }
@@ -548,7 +550,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const 
 #pragma unroll
         for (int q = 0; q < 2; ++q)
           res[i][q] = okp[i] && d.okc[q]
-                          ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.residual) + r_off + d.c2[q])
+                          ? *reinterpret_cast<const uint4*>(reinterpret_cast<const h16_t*>(p.residual) + r_off + d.c2[q])
                           : make_uint4(0, 0, 0, 0);
       }
     }
@@ -645,33 +647,33 @@ struct PatchDecode {
 
 // LDS read the compiler does not track: the caller waits with lgkm_wait before using dst.
 template <int OFF>
-__device__ __forceinline__ void ds_read_b128_at(bf16x8& dst, unsigned addr) {
+__device__ __forceinline__ void ds_read_b128_at(h16x8& dst, unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds_read immediate offset is 16 bits");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 }
 // Waits until at most CNT LDS operations are outstanding; `frag` is threaded through so that
 // its consumer cannot be scheduled above the wait.
 template <int CNT>
-__device__ __forceinline__ void lgkm_wait(bf16x8& frag) {
+__device__ __forceinline__ void lgkm_wait(h16x8& frag) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(CNT));
 }
 
 
 // Waits until at most CNT LDS operations are outstanding, threading several fragments through.
 template <int CNT>
-__device__ __forceinline__ void lgkm_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+__device__ __forceinline__ void lgkm_wait(h16x8& a, h16x8& b, h16x8& c, h16x8& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(CNT));
 }
 template <int CNT>
-__device__ __forceinline__ void lgkm_wait(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d, bf16x8& e) {
+__device__ __forceinline__ void lgkm_wait(h16x8& a, h16x8& b, h16x8& c, h16x8& d, h16x8& e) {
   asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e) : "n"(CNT));
 }
 
 // Waits for every outstanding LDS operation; the 12 fragments of a K step are threaded through.
-__device__ __forceinline__ void lgkm_wait12(bf16x8 (&x)[12]) {
+__device__ __forceinline__ void lgkm_wait12(h16x8 (&x)[12]) {
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]),
                  "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
 }
 
-}  // namespace miseg
+}  // namespace MISEG_KNS

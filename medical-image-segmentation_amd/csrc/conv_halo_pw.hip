@@ -25,7 +25,7 @@
 // each other's halo swaps, prologues and epilogues.
 #include "conv_common.h"
 
-namespace miseg {
+namespace MISEG_KNS {
 
 namespace {
 
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   const unsigned xl_base = (unsigned)(unsigned long long)(lds_byte*)xlane;
   const unsigned wr = (unsigned)(unsigned long long)(lds_byte*)wring;
-  bf16x8 xf[MT], wf[2];
+  h16x8 xf[MT], wf[2];
 #define MISEG_DS_READ(dst, addr, off) ds_read_b128_at<off>(dst, addr)
 #define MISEG_LGKM_WAIT(frag, cnt) lgkm_wait<cnt>(frag)
 
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
             constexpr int younger = (MT - 1 - b) + (prev_w ? 1 : 0) + (has_x ? b : 0);
             MISEG_LGKM_WAIT(xf[b], younger);
           }
-          acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1], xf[b], acc[0][b], 0, 0, 0);
+          acc[0][b] = mfma_32x32x16(wf[kk & 1], xf[b], acc[0][b]);
           if constexpr (has_x)
             MISEG_DS_READ(xf[b], xl, ((b + (DGT ? 1 - ntap / TAPW : ntap / TAPW)) * HWD +
                                       (DGT ? 1 - ntap % TAPW : ntap % TAPW)) * PITCH + nkk * 32);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_ks_kernel(const ConvParam
   int wlane[2];
 #pragma unroll
   for (int sidx = 0; sidx < 2; ++sidx) wlane[sidx] = swz64(lrow, sidx * 2 + lhalf);
-  bf16x8 xf[MT], wf[2];
+  h16x8 xf[MT], wf[2];
 
   issue_halo(0);
   issue_next();
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_ks_kernel(const ConvParam
             constexpr int younger = (MT - 1 - b) + (prev_w ? 1 : 0) + (has_x ? b : 0);
             lgkm_wait<younger>(xf[b]);
           }
-          acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[sidx], xf[b], acc[0][b], 0, 0, 0);
+          acc[0][b] = mfma_32x32x16(wf[sidx], xf[b], acc[0][b]);
           if constexpr (has_x)
             ds_read_b128_at<((b + ntap / TAPW) * HWD + ntap % TAPW) * PITCH + ns * 32>(xf[b], xl);
           if constexpr (b == MT - 1 && has_w) {
@@ -555,12 +555,12 @@ __global__ __launch_bounds__(256, 1) void convT_c64_kernel(const ConvParams p) {
 
   // ---- weights of phases (ph_a, 0) and (ph_a, 1): fragment [pb][tap][kk] = cout lrow,
   //      k = kk * 16 + lhalf * 8 .. + 7 of tap `tap` ----
-  bf16x8 wreg[2][4][4];
+  h16x8 wreg[2][4][4];
   static_for<32>([&](auto ic) __attribute__((always_inline)) {
     constexpr int pb = decltype(ic)::value >> 4, tap = (decltype(ic)::value >> 2) & 3, kk = decltype(ic)::value & 3;
     // rows past Cout repeat row 0: their results are never stored
-    const bf16_t* wsrc = p.weight + (long long)(ph_a * 2 + pb) * p.Cout * 4 * 64 + (lrow < p.Cout ? lrow : 0) * 4 * 64 + lhalf * 8;
-    wreg[pb][tap][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wsrc + tap * 64 + kk * 16));
+    const h16_t* wsrc = p.weight + (long long)(ph_a * 2 + pb) * p.Cout * 4 * 64 + (lrow < p.Cout ? lrow : 0) * 4 * 64 + lhalf * 8;
+    wreg[pb][tap][kk] = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(wsrc + tap * 64 + kk * 16));
   });
   // ---- halo requests: lane constants (position inside the halo) + per-patch origin ----
   // (one word per request: halo row | column << 8 | 16-byte slot << 16, or -1 for padding)
@@ -645,9 +645,9 @@ __global__ __launch_bounds__(256, 1) void convT_c64_kernel(const ConvParams p) {
     f32x16 acc[2][1][4];   // [column phase][.][row]
     zero_acc<4, 1>(acc[0]);
     zero_acc<4, 1>(acc[1]);
-    bf16x8 xf[2][12];
+    h16x8 xf[2][12];
     // K step s = (dy, kk): 12 fragment reads (4 rows x 3 columns) one step ahead of 16 MFMAs
-    auto read_step = [&](auto sc_, bf16x8 (&x)[12]) __attribute__((always_inline)) {
+    auto read_step = [&](auto sc_, h16x8 (&x)[12]) __attribute__((always_inline)) {
       constexpr int s = decltype(sc_)::value;
       constexpr int dy = s >> 2, kk = s & 3;
       static_for<12>([&](auto ic) __attribute__((always_inline)) {
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void convT_c64_kernel(const ConvParams p) {
         ds_read_b128_at<((i / 3 + dy) * HWD + i % 3) * PITCH + kk * 32>(x[i], xl);
       });
     };
-    auto wait_step = [&](bf16x8 (&x)[12]) __attribute__((always_inline)) { lgkm_wait12(x); };
+    auto wait_step = [&](h16x8 (&x)[12]) __attribute__((always_inline)) { lgkm_wait12(x); };
     read_step(std::integral_constant<int, 0>{}, xf[0]);
     wait_step(xf[0]);
     static_for<8>([&](auto sc_) __attribute__((always_inline)) {
@@ -666,8 +666,7 @@ __global__ __launch_bounds__(256, 1) void convT_c64_kernel(const ConvParams p) {
       static_for<16>([&](auto mc) __attribute__((always_inline)) {
         constexpr int m = decltype(mc)::value;
         constexpr int dx = m >> 3, b = (m >> 1) & 3, pb = m & 1;
-        acc[pb][0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[pb][dy * 2 + dx][kk],
-                                                                xf[s & 1][b * 3 + pb + dx], acc[pb][0][b], 0, 0, 0);
+        acc[pb][0][b] = mfma_32x32x16(wreg[pb][dy * 2 + dx][kk], xf[s & 1][b * 3 + pb + dx], acc[pb][0][b]);
       });
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (s < 7) wait_step(xf[(s + 1) & 1]);
@@ -686,7 +685,7 @@ __global__ __launch_bounds__(256, 1) void convT_c64_kernel(const ConvParams p) {
     if (direct) {
       {
         // scale | shift of couts [8h, 8h + 8) and [16 + 8h, 16 + 8h + 8)
-        bf16x8 c[8];
+        h16x8 c[8];
         ds_read_b128_at<0>(c[0], coef_a);
         ds_read_b128_at<16>(c[1], coef_a);
         ds_read_b128_at<64>(c[2], coef_a);
@@ -762,4 +761,4 @@ hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-}  // namespace miseg
+}  // namespace MISEG_KNS

@@ -23,7 +23,7 @@
 // two blocks per CU.
 #include "conv_common.h"
 
-namespace miseg {
+namespace MISEG_KNS {
 
 namespace {
 constexpr int HF_TH = 8, HF_TW = 32;
@@ -48,7 +48,7 @@ constexpr int HF_SCR_WAVE = 1024 + 256;
 constexpr int HF_SS_OFF = HF_SCR_OFF + 4 * HF_SCR_WAVE;   // body scale[32], shift[32] (fp32)
 constexpr int HF_LDS = HF_SS_OFF + 256;
 static_assert(2 * HF_LDS <= 160 * 1024, "two blocks per CU");
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef f32x4_t f32x4;
 
 // Workgroup barrier for LDS hand-offs between waves: this wave's LDS operations have completed
 // (lgkmcnt), then s_barrier.  __syncthreads() would also drain vmcnt -- the LDS-DMA requests of the
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
   const int per_img = p.tiles_y * p.tiles_x;
   const int r16 = lane >> 2;
   const int slot = lane & 3;
-  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line) + slot * 8;
+  const h16_t* zero_src = reinterpret_cast<const h16_t*>(g_zero_line) + slot * 8;
   const int lrow = lane & 31;
   const int lhalf = lane >> 5;
 
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
   auto issue_halo = [&](int tile, int buf) {
     int n, y0, x0;
     patch_origin(tile, n, y0, x0);
-    const bf16_t* img = p.in + n * p.in_img_stride;
+    const h16_t* img = p.in + n * p.in_img_stride;
 #pragma unroll
     for (int j = 0; j < (HF_NII + 3) / 4; ++j) {
       const int i = j * 4 + wave;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
         const int ix = x0 - 2 + hx;
         const bool ok = hr < HF_IROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const int ch = slot ^ ((hr >> 2) & 3);
-        const bf16_t* src = ok ? img + (long long)iy * p.in_row_stride + (long long)ix * p.in_pix_stride + ch * 8
+        const h16_t* src = ok ? img + (long long)iy * p.in_row_stride + (long long)ix * p.in_pix_stride + ch * 8
                                : zero_src;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)src,
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
       const int tap = wr >> 5;
       const int co = wr & 31;
       const int ch = slot ^ ((wr >> 2) & 3);
-      const bf16_t* src = co < p.Cout ? p.weight + ((long long)co * 9 + tap) * 32 + ch * 8 : zero_src;
+      const h16_t* src = co < p.Cout ? p.weight + ((long long)co * 9 + tap) * 32 + ch * 8 : zero_src;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)(lds + HF_BW_OFF + i * 1024), 16, 0, 0);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
     {
       const unsigned inb_a = lds_a + cur * HF_IN_BYTES;
       const unsigned wb_a[2] = {lds_a + HF_BW_OFF + swz64(lrow, lhalf), lds_a + HF_BW_OFF + swz64(lrow, 2 + lhalf)};
-      bf16x8 fw[2], fx[2][BT];
+      h16x8 fw[2], fx[2][BT];
       auto issue = [&](auto sc_) __attribute__((always_inline)) {
         constexpr int st = decltype(sc_)::value;
         constexpr int tap = st >> 1, kk = st & 1, dy = tap / 3, dx = tap % 3;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
           lgkm_wait<0>(fw[st & 1], fx[st & 1][0], fx[st & 1][1], fx[st & 1][2]);
 #pragma unroll
         for (int t = 0; t < BT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[st & 1], fx[st & 1][t], acc[t], 0, 0, 0);
+          acc[t] = mfma_32x32x16(fw[st & 1], fx[st & 1][t], acc[t]);
         if constexpr (st + 2 < 18) issue(std::integral_constant<int, st + 2>{});
       });
     }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
     // halo of the NEXT patch, because it cannot tell the read apart from the LDS-DMA's target)
     float4 sc[4], sh[4];
     {
-      bf16x8 raw[8];
+      h16x8 raw[8];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         ds_read_b128_at<0>(raw[g], lds_a + HF_SS_OFF + (8 * g + 4 * lhalf) * 4);
@@ -242,10 +242,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
           float v1 = acc[t][4 * g + 1] * sc[g].y + sh[g].y;
           float v2 = acc[t][4 * g + 2] * sc[g].z + sh[g].z;
           float v3 = acc[t][4 * g + 3] * sc[g].w + sh[g].w;
-          if (p.act == MISEG_ACT_RELU) {
-            v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
-          }
-          uint2 o = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+          const bool relu = p.act == MISEG_ACT_RELU;
+          v0 = h16_act(v0, relu); v1 = h16_act(v1, relu); v2 = h16_act(v2, relu); v3 = h16_act(v3, relu);
+          uint2 o = make_uint2(pack_h16x2_raw(v0, v1), pack_h16x2_raw(v2, v3));
           if (!inside) o = make_uint2(0, 0);
           // by hand for the same reason as the scale/shift reads above
           asm volatile("ds_write_b64 %0, %1" ::"v"(mid_w[t] + g * 16), "v"(o) : "memory");
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
       // this lane's pixel (row 2*wave, x = hn) and 8-channel group of the intermediate tile
       const unsigned mid_a = lds_a + cur * HF_IN_BYTES + (2 * wave * HF_MW + hn) * HF_MPITCH + kg * 16;
       const unsigned cw_a = lds_a + HF_CW_OFF + (lane & 3) * 64 + kg * 16;
-      bf16x8 fw[2], fx[2][4];
+      h16x8 fw[2], fx[2][4];
       auto issue = [&](auto tc_) __attribute__((always_inline)) {
         constexpr int tap = decltype(tc_)::value;
         constexpr int dy = tap / 3, dx = tap % 3;
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
           lgkm_wait<0>(fw[tap & 1], fx[tap & 1][0], fx[tap & 1][1], fx[tap & 1][2], fx[tap & 1][3]);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
-          hacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[tap & 1], fx[tap & 1][t], hacc[t], 0, 0, 0);
+          hacc[t] = mfma_16x16x32(fw[tap & 1], fx[tap & 1][t], hacc[t]);
         if constexpr (tap + 2 < 9) issue(std::integral_constant<int, tap + 2>{});
       });
     }
@@ -366,4 +365,4 @@ hipError_t launch_c32_head(const ConvParams& body, const ConvParams& head, dim3 
   return hipGetLastError();
 }
 
-}  // namespace miseg
+}  // namespace MISEG_KNS

@@ -16,7 +16,7 @@
 // register-staged path (BK = 32) that can apply BatchNorm+ReLU to the operand on the way.
 #include "conv_common.h"
 
-namespace miseg {
+namespace MISEG_KNS {
 
 // ---------------------------------------------------------------------------------
 // Kernel A: register-staged, BK = 32.  Serves operands that need the BatchNorm+ReLU
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int srow = tid >> 2;
   const int chunk = tid & 3;
 
-  const bf16_t* a_ptr[PA];
+  const h16_t* a_ptr[PA];
   int a_iy0[PA], a_ix0[PA];
   bool a_ok[PA];
 #pragma unroll
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     a_ptr[i] = p.in + n * p.in_img_stride + (long long)a_iy0[i] * p.in_row_stride +
                (long long)a_ix0[i] * p.in_pix_stride + chunk * 8;
   }
-  const bf16_t* w_ptr[PB];
+  const h16_t* w_ptr[PB];
   bool w_ok[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
@@ -98,14 +98,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       if (ok) {
         v = *reinterpret_cast<const uint4*>(a_ptr[i] + aoff);
         if (PRO) {
-          v.x = pack_bf16x2(fmaxf(bf16lo_to_f32(v.x) * s0.x + t0.x, 0.f),
-                            fmaxf(bf16hi_to_f32(v.x) * s0.y + t0.y, 0.f));
-          v.y = pack_bf16x2(fmaxf(bf16lo_to_f32(v.y) * s0.z + t0.z, 0.f),
-                            fmaxf(bf16hi_to_f32(v.y) * s0.w + t0.w, 0.f));
-          v.z = pack_bf16x2(fmaxf(bf16lo_to_f32(v.z) * s1.x + t1.x, 0.f),
-                            fmaxf(bf16hi_to_f32(v.z) * s1.y + t1.y, 0.f));
-          v.w = pack_bf16x2(fmaxf(bf16lo_to_f32(v.w) * s1.z + t1.z, 0.f),
-                            fmaxf(bf16hi_to_f32(v.w) * s1.w + t1.w, 0.f));
+          v.x = pack_h16x2_raw(h16_relu(h16lo_to_f32(v.x) * s0.x + t0.x), h16_relu(h16hi_to_f32(v.x) * s0.y + t0.y));
+          v.y = pack_h16x2_raw(h16_relu(h16lo_to_f32(v.y) * s0.z + t0.z), h16_relu(h16hi_to_f32(v.y) * s0.w + t0.w));
+          v.z = pack_h16x2_raw(h16_relu(h16lo_to_f32(v.z) * s1.x + t1.x), h16_relu(h16hi_to_f32(v.z) * s1.y + t1.y));
+          v.w = pack_h16x2_raw(h16_relu(h16lo_to_f32(v.w) * s1.z + t1.z), h16_relu(h16hi_to_f32(v.w) * s1.w + t1.w));
         }
       }
       ra[i] = v;
@@ -144,20 +140,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ch = kk * 2 + lhalf;
-      bf16x8 xf[MT], wf[NT];
+      h16x8 xf[MT], wf[NT];
 #pragma unroll
       for (int b = 0; b < MT; ++b)
-        xf[b] = *reinterpret_cast<const bf16x8*>(
+        xf[b] = *reinterpret_cast<const h16x8*>(
             lds + buf * STAGE + swz64(wm * (MT * 32) + b * 32 + lrow, ch));
 #pragma unroll
       for (int a = 0; a < NT; ++a)
-        wf[a] = *reinterpret_cast<const bf16x8*>(
+        wf[a] = *reinterpret_cast<const h16x8*>(
             lds + buf * STAGE + BOFF + swz64(wn * (NT * 32) + a * 32 + lrow, ch));
 #pragma unroll
       for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma_32x32x16(wf[a], xf[b], acc[a][b]);
     }
   };
 
@@ -212,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
   const int r8 = lane >> 3;
   const int slot = lane & 7;
 
-  const bf16_t* a_ptr[NA];
+  const h16_t* a_ptr[NA];
   int a_iy0[NA], a_ix0[NA];
   bool a_ok[NA];
 #pragma unroll
@@ -231,7 +227,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     a_ptr[j] = p.in + n * p.in_img_stride + (long long)a_iy0[j] * p.in_row_stride +
                (long long)a_ix0[j] * p.in_pix_stride + ch * 8;
   }
-  const bf16_t* w_ptr[NB];
+  const h16_t* w_ptr[NB];
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int row = (4 * j + wave) * 8 + r8;
@@ -239,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     const int ch = slot ^ ((row >> 1) & 7);
     w_ptr[j] = co < p.Cout ? tc.wbase + (long long)co * KK * p.Cin + ch * 8 : nullptr;
   }
-  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line) + slot * 8;
+  const h16_t* zero_src = reinterpret_cast<const h16_t*>(g_zero_line) + slot * 8;
 
   int dy = 0, dx = 0, cc = 0;
   auto issue = [&](int ks, int buf) {
@@ -248,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     for (int j = 0; j < NA; ++j) {
       const bool ok = a_ok[j] && (unsigned)(a_iy0[j] + dy) < (unsigned)p.H &&
                       (unsigned)(a_ix0[j] + dx) < (unsigned)p.W;
-      const bf16_t* src = ok ? a_ptr[j] + aoff : zero_src;
+      const h16_t* src = ok ? a_ptr[j] + aoff : zero_src;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)(lds + buf * STAGE + (4 * j + wave) * 1024),
@@ -256,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const bf16_t* src = w_ptr[j] ? w_ptr[j] + ks * 64 : zero_src;
+      const h16_t* src = w_ptr[j] ? w_ptr[j] + ks * 64 : zero_src;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)(lds + buf * STAGE + BOFF +
@@ -279,14 +275,14 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
 
   auto compute = [&](int buf) __attribute__((always_inline)) {
     // fragment reads run two 16-deep sub-steps ahead of the MFMAs that consume them
-    bf16x8 xf[2][MT], wf[2][NT];
+    h16x8 xf[2][MT], wf[2][NT];
 #define MISEG_RD(KK)                                                                        \
   {                                                                                         \
     const int ch = (KK) * 2 + lhalf;                                                        \
     _Pragma("unroll") for (int b = 0; b < MT; ++b) xf[(KK) & 1][b] =                        \
-        *reinterpret_cast<const bf16x8*>(lds + buf * STAGE + swz128(wm * (MT * 32) + b * 32 + lrow, ch));                                               \
+        *reinterpret_cast<const h16x8*>(lds + buf * STAGE + swz128(wm * (MT * 32) + b * 32 + lrow, ch));                                               \
     _Pragma("unroll") for (int a = 0; a < NT; ++a) wf[(KK) & 1][a] =                        \
-        *reinterpret_cast<const bf16x8*>(lds + buf * STAGE + BOFF + swz128(wn * (NT * 32) + a * 32 + lrow, ch));                                               \
+        *reinterpret_cast<const h16x8*>(lds + buf * STAGE + BOFF + swz128(wn * (NT * 32) + a * 32 + lrow, ch));                                               \
   }
     MISEG_RD(0)
     MISEG_RD(1)
@@ -297,8 +293,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p)
       for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][a], xf[kk & 1][b],
-                                                              acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma_32x32x16(wf[kk & 1][a], xf[kk & 1][b], acc[a][b]);
       if (kk + 2 < 4) MISEG_RD(kk + 2)
     }
 #undef MISEG_RD
@@ -373,10 +368,10 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
   const int steps = nchunk * TAPS;
   const int r8 = lane >> 3;
   const int slot = lane & 7;
-  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line) + slot * 8;
+  const h16_t* zero_src = reinterpret_cast<const h16_t*>(g_zero_line) + slot * 8;
 
   // halo sources: instruction j of this wave fills halo rows [(j*NW + wave)*8, +8)
-  const bf16_t* h_src[NHW];
+  const h16_t* h_src[NHW];
 #pragma unroll
   for (int j = 0; j < NHW; ++j) {
     const int hr = (j * NW + wave) * 8 + r8;
@@ -390,7 +385,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
                         (long long)ix * p.in_pix_stride + ch * 8
                   : nullptr;
   }
-  const bf16_t* w_src[NBW];
+  const h16_t* w_src[NBW];
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
     const int row = (j * NW + wave) * 8 + r8;
@@ -401,7 +396,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
 
   auto issue_halo = [&](int j, int chunk, int hb) {
     if ((j * NW + wave) < NHI) {
-      const bf16_t* src = h_src[j] ? h_src[j] + chunk * 64 : zero_src;
+      const h16_t* src = h_src[j] ? h_src[j] + chunk * 64 : zero_src;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)(lds + hb * HALO_BYTES + (j * NW + wave) * 1024),
@@ -412,7 +407,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
 #pragma unroll
     for (int j = 0; j < NBW; ++j) {
       if ((j * NW + wave) < NBI) {
-        const bf16_t* src = w_src[j] ? w_src[j] + tap * p.Cin + chunk * 64 : zero_src;
+        const h16_t* src = w_src[j] ? w_src[j] + tap * p.Cin + chunk * 64 : zero_src;
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)src,
             (__attribute__((address_space(3))) void*)(lds + WOFF + wb * W_BYTES +
@@ -443,14 +438,14 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
       hsw[b] = (hrow[b] >> 1) & 7;
     }
     // fragment reads run two 16-deep sub-steps ahead of the MFMAs that consume them
-    bf16x8 xf[2][MT], wf[2][NT];
+    h16x8 xf[2][MT], wf[2][NT];
 #define MISEG_RD(KK)                                                                        \
   {                                                                                         \
     const int ch = (KK) * 2 + lhalf;                                                        \
     _Pragma("unroll") for (int b = 0; b < MT; ++b) xf[(KK) & 1][b] =                        \
-        *reinterpret_cast<const bf16x8*>(hbase + hrow[b] * 128 + ((ch ^ hsw[b]) << 4));                                               \
+        *reinterpret_cast<const h16x8*>(hbase + hrow[b] * 128 + ((ch ^ hsw[b]) << 4));                                               \
     _Pragma("unroll") for (int a = 0; a < NT; ++a) wf[(KK) & 1][a] =                        \
-        *reinterpret_cast<const bf16x8*>(wbase + swz128(wn * (NT * 32) + a * 32 + lrow, ch));                                               \
+        *reinterpret_cast<const h16x8*>(wbase + swz128(wn * (NT * 32) + a * 32 + lrow, ch));                                               \
   }
     MISEG_RD(0)
     MISEG_RD(1)
@@ -461,8 +456,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv3x3_halo_kernel(co
       for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][a], xf[kk & 1][b],
-                                                              acc[a][b], 0, 0, 0);
+          acc[a][b] = mfma_32x32x16(wf[kk & 1][a], xf[kk & 1][b], acc[a][b]);
       if (kk + 2 < 4) MISEG_RD(kk + 2)
     }
 #undef MISEG_RD
@@ -551,7 +545,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const ConvParams p) {
   const int x0 = (trem - tyi * p.tiles_x) * TW;
   const int r16 = lane >> 2;
   const int slot = lane & 3;
-  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line) + slot * 8;
+  const h16_t* zero_src = reinterpret_cast<const h16_t*>(g_zero_line) + slot * 8;
 
 #pragma unroll
   for (int j = 0; j < NHW; ++j) {
@@ -564,7 +558,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const ConvParams p) {
       const int ix = x0 - 1 + hx;
       const bool ok = hr < HROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       const int ch = slot ^ ((hr >> 2) & 3);
-      const bf16_t* src = ok ? p.in + n * p.in_img_stride + (long long)iy * p.in_row_stride +
+      const h16_t* src = ok ? p.in + n * p.in_img_stride + (long long)iy * p.in_row_stride +
                                    (long long)ix * p.in_pix_stride + ch * 8
                              : zero_src;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -580,7 +574,7 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const ConvParams p) {
       const int tap = wr >> 5;
       const int co = wr & 31;
       const int ch = slot ^ ((wr >> 2) & 3);
-      const bf16_t* src = co < p.Cout ? tc.wbase + ((long long)co * 9 + tap) * 32 + ch * 8 : zero_src;
+      const h16_t* src = co < p.Cout ? tc.wbase + ((long long)co * 9 + tap) * 32 + ch * 8 : zero_src;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)(lds + HALO_BYTES + i * 1024), 16, 0, 0);
@@ -606,12 +600,12 @@ __global__ __launch_bounds__(256) void conv3x3_c32_kernel(const ConvParams p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int ch = kk * 2 + lhalf;
-      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(lds + HALO_BYTES + swz64(tap * 32 + lrow, ch));
+      const h16x8 wf = *reinterpret_cast<const h16x8*>(lds + HALO_BYTES + swz64(tap * 32 + lrow, ch));
 #pragma unroll
       for (int b = 0; b < MT; ++b) {
         const int hrow = hr0[b] + dy * HWD + dx;
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(lds + swz64(hrow, ch));
-        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[0][b], 0, 0, 0);
+        const h16x8 xf = *reinterpret_cast<const h16x8*>(lds + swz64(hrow, ch));
+        acc[0][b] = mfma_32x32x16(wf, xf, acc[0][b]);
       }
     }
   }
@@ -855,10 +849,10 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
 }
 
 static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
-  p.in = (const bf16_t*)d->in;
-  p.weight = (const bf16_t*)d->weight;
+  p.in = (const h16_t*)d->in;
+  p.weight = (const h16_t*)d->weight;
   p.out = d->out;
-  p.out2 = (bf16_t*)d->out2;
+  p.out2 = (h16_t*)d->out2;
   p.residual = d->residual;
   p.scale = d->scale;
   p.shift = d->shift;
@@ -1092,4 +1086,4 @@ int launch_conv_c32_head(const miseg_conv_desc* b, const miseg_conv_desc* h, hip
   return MISEG_OK;
 }
 
-}  // namespace miseg
+}  // namespace MISEG_KNS

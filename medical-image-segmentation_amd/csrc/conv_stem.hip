@@ -15,7 +15,7 @@
 // consecutive stores complete the 128 bytes of a pixel.
 #include "conv_common.h"
 
-namespace miseg {
+namespace MISEG_KNS {
 
 namespace {
 constexpr int ST_TH = 8, ST_TW = 32;
@@ -41,12 +41,12 @@ __global__ __launch_bounds__(256, 2) void conv_stem7_kernel(const ConvParams p) 
   const int row_bytes = p.in_row_stride * 2;
 
   // ---- weights: fragment [ky][s][g] = cout 32 g + lrow, window values 16 s + 8 lhalf .. + 7 ----
-  bf16x8 wreg[7][2][2];
+  h16x8 wreg[7][2][2];
   static_for<28>([&](auto ic) __attribute__((always_inline)) {
     constexpr int ky = decltype(ic)::value >> 2, s = (decltype(ic)::value >> 1) & 1, g = decltype(ic)::value & 1;
     const int co = g * 32 + lrow;
-    const bf16_t* wsrc = p.weight + ((co < p.Cout ? co : 0) * 7 + ky) * 32 + s * 16 + lhalf * 8;
-    wreg[ky][s][g] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wsrc));
+    const h16_t* wsrc = p.weight + ((co < p.Cout ? co : 0) * 7 + ky) * 32 + s * 16 + lhalf * 8;
+    wreg[ky][s][g] = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(wsrc));
   });
   // ---- epilogue coefficients wait in LDS between patches: scale[64] | shift[64] ----
   float* coef = reinterpret_cast<float*>(lds + 2 * ST_BUF);
@@ -115,8 +115,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem7_kernel(const ConvParams p) 
       for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][g][r] = 0.f;
-    bf16x8 xf[2][2];   // [region row parity][s]
-    auto read_row = [&](auto rc, bf16x8 (&x)[2]) __attribute__((always_inline)) {
+    h16x8 xf[2][2];   // [region row parity][s]
+    auto read_row = [&](auto rc, h16x8 (&x)[2]) __attribute__((always_inline)) {
       constexpr int r = decltype(rc)::value;
       ds_read_b128_at<r * ST_ROWB>(x[0], xl);
       ds_read_b128_at<r * ST_ROWB + 32>(x[1], xl);
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(256, 2) void conv_stem7_kernel(const ConvParams p) 
       static_for<4>([&](auto ic) __attribute__((always_inline)) {
         constexpr int s = decltype(ic)::value >> 1, g = decltype(ic)::value & 1;
         if constexpr (r <= 6)
-          acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[r][s][g], xf[r & 1][s], acc[0][g], 0, 0, 0);
+          acc[0][g] = mfma_32x32x16(wreg[r][s][g], xf[r & 1][s], acc[0][g]);
         if constexpr (r >= 2)
-          acc[1][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[r - 2][s][g], xf[r & 1][s], acc[1][g], 0, 0, 0);
+          acc[1][g] = mfma_32x32x16(wreg[r - 2][s][g], xf[r & 1][s], acc[1][g]);
       });
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (r + 2 < 9) read_row(std::integral_constant<int, r + 2>{}, xf[r & 1]);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void conv_stem7_kernel(const ConvParams p) 
       dl.relu = relu;
       {
         // scale | shift of couts [32g + 8h, + 8) and [32g + 16 + 8h, + 8)
-        bf16x8 c[8];
+        h16x8 c[8];
         ds_read_b128_at<g * 128 + 0>(c[0], coef_a);
         ds_read_b128_at<g * 128 + 16>(c[1], coef_a);
         ds_read_b128_at<g * 128 + 64>(c[2], coef_a);
@@ -209,4 +209,4 @@ hipError_t launch_conv_stem7(ConvParams p, hipStream_t s) {
   return hipGetLastError();
 }
 
-}  // namespace miseg
+}  // namespace MISEG_KNS

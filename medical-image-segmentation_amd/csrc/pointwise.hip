@@ -4,7 +4,7 @@
 // of wider buffers; every thread moves 16 bytes (8 bf16 channels) per access.
 #include "common.h"
 
-namespace miseg {
+namespace MISEG_KNS {
 
 static inline int grid_for(long long work, int block = 256) {
   long long g = (work + block - 1) / block;
@@ -20,7 +20,7 @@ static inline int grid_for(long long work, int block = 256) {
 // IND: channel 3 = 1 inside the image (the indicator the training path uses to obtain the input
 // BatchNorm's beta gradient from the stem's weight gradient), else 0 everywhere
 template <bool IND>
-__global__ void prep_input_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+__global__ void prep_input_kernel(const float* __restrict__ in, h16_t* __restrict__ out,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   int N, int H, int W) {
   const int Hp = H + 6, Wp = W + 8;
@@ -37,8 +37,8 @@ __global__ void prep_input_kernel(const float* __restrict__ in, bf16_t* __restri
     uint2 v = make_uint2(0, 0);
     if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
       const float* px = in + (((long long)n * H + y) * W + x) * 3;
-      v.x = pack_bf16x2(px[0] * s0 + t0, px[1] * s1 + t1);
-      v.y = pack_bf16x2(px[2] * s2 + t2, IND ? 1.f : 0.f);
+      v.x = pack_h16x2(px[0] * s0 + t0, px[1] * s1 + t1);
+      v.y = pack_h16x2(px[2] * s2 + t2, IND ? 1.f : 0.f);
     }
     *reinterpret_cast<uint2*>(out + i * 4) = v;
   }
@@ -51,10 +51,10 @@ int launch_prep_input(const float* in, void* out, const float* scale, const floa
                   "prep_input: H and W must be positive and even");
   const long long total = (long long)N * (H + 6) * (W + 8);
   if (indicator)
-    hipLaunchKernelGGL(prep_input_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, in, (bf16_t*)out,
+    hipLaunchKernelGGL(prep_input_kernel<true>, dim3(grid_for(total)), dim3(256), 0, s, in, (h16_t*)out,
                        scale, shift, N, H, W);
   else
-    hipLaunchKernelGGL(prep_input_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, in, (bf16_t*)out,
+    hipLaunchKernelGGL(prep_input_kernel<false>, dim3(grid_for(total)), dim3(256), 0, s, in, (h16_t*)out,
                        scale, shift, N, H, W);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
@@ -64,23 +64,23 @@ int launch_prep_input(const float* in, void* out, const float* scale, const floa
 // max pool 3x3 stride 2 after zero pad 1 (inputs are post-ReLU, so 0 == -inf padding)
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void max8(float (&m)[8], const uint4 v) {
-  m[0] = fmaxf(m[0], bf16lo_to_f32(v.x)); m[1] = fmaxf(m[1], bf16hi_to_f32(v.x));
-  m[2] = fmaxf(m[2], bf16lo_to_f32(v.y)); m[3] = fmaxf(m[3], bf16hi_to_f32(v.y));
-  m[4] = fmaxf(m[4], bf16lo_to_f32(v.z)); m[5] = fmaxf(m[5], bf16hi_to_f32(v.z));
-  m[6] = fmaxf(m[6], bf16lo_to_f32(v.w)); m[7] = fmaxf(m[7], bf16hi_to_f32(v.w));
+  m[0] = fmaxf(m[0], h16lo_to_f32(v.x)); m[1] = fmaxf(m[1], h16hi_to_f32(v.x));
+  m[2] = fmaxf(m[2], h16lo_to_f32(v.y)); m[3] = fmaxf(m[3], h16hi_to_f32(v.y));
+  m[4] = fmaxf(m[4], h16lo_to_f32(v.z)); m[5] = fmaxf(m[5], h16hi_to_f32(v.z));
+  m[6] = fmaxf(m[6], h16lo_to_f32(v.w)); m[7] = fmaxf(m[7], h16hi_to_f32(v.w));
 }
 __device__ __forceinline__ void unpack8(float (&m)[8], const uint4 v) {
-  m[0] = bf16lo_to_f32(v.x); m[1] = bf16hi_to_f32(v.x);
-  m[2] = bf16lo_to_f32(v.y); m[3] = bf16hi_to_f32(v.y);
-  m[4] = bf16lo_to_f32(v.z); m[5] = bf16hi_to_f32(v.z);
-  m[6] = bf16lo_to_f32(v.w); m[7] = bf16hi_to_f32(v.w);
+  m[0] = h16lo_to_f32(v.x); m[1] = h16hi_to_f32(v.x);
+  m[2] = h16lo_to_f32(v.y); m[3] = h16hi_to_f32(v.y);
+  m[4] = h16lo_to_f32(v.z); m[5] = h16hi_to_f32(v.z);
+  m[6] = h16lo_to_f32(v.w); m[7] = h16hi_to_f32(v.w);
 }
 __device__ __forceinline__ uint4 pack8(const float (&m)[8]) {
-  return make_uint4(pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]),
-                    pack_bf16x2(m[6], m[7]));
+  return make_uint4(pack_h16x2(m[0], m[1]), pack_h16x2(m[2], m[3]), pack_h16x2(m[4], m[5]),
+                    pack_h16x2(m[6], m[7]));
 }
 
-__global__ void maxpool3x3s2_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+__global__ void maxpool3x3s2_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out,
                                     const float* __restrict__ scale,
                                     const float* __restrict__ shift, int N, int H, int W, int C,
                                     int ips, int ops) {
@@ -126,8 +126,8 @@ int launch_maxpool3x3s2(const void* in, void* out, const float* scale, const flo
                   "maxpool: C and strides must be multiples of 8");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long long total = (long long)N * Ho * Wo * (C >> 3);
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in,
-                     (bf16_t*)out, scale, shift, N, H, W, C, ips, ops);
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const h16_t*)in,
+                     (h16_t*)out, scale, shift, N, H, W, C, ips, ops);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
 }
@@ -135,7 +135,7 @@ int launch_maxpool3x3s2(const void* in, void* out, const float* scale, const flo
 // ---------------------------------------------------------------------------------
 // average pool 2x2 stride 2
 // ---------------------------------------------------------------------------------
-__global__ void avgpool2x2_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int N,
+__global__ void avgpool2x2_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out, int N,
                                   int H, int W, int C, int ips, int ops) {
   const int Ho = H >> 1, Wo = W >> 1, C8 = C >> 3;
   const long long total = (long long)N * Ho * Wo * C8;
@@ -172,8 +172,8 @@ int launch_avgpool2x2(const void* in, void* out, int N, int H, int W, int C, int
                       (ops & 7) == 0 && ips >= C && ops >= C,
                   "avgpool: C and strides must be multiples of 8");
   const long long total = (long long)N * (H >> 1) * (W >> 1) * (C >> 3);
-  hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const bf16_t*)in,
-                     (bf16_t*)out, N, H, W, C, ips, ops);
+  hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const h16_t*)in,
+                     (h16_t*)out, N, H, W, C, ips, ops);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
 }
@@ -181,9 +181,9 @@ int launch_avgpool2x2(const void* in, void* out, int N, int H, int W, int C, int
 // ---------------------------------------------------------------------------------
 // nearest upsample by 2^shift, optional add
 // ---------------------------------------------------------------------------------
-__global__ void upsample_nearest_kernel(const bf16_t* __restrict__ in,
-                                        const bf16_t* __restrict__ addend,
-                                        bf16_t* __restrict__ out, int N, int H, int W, int C,
+__global__ void upsample_nearest_kernel(const h16_t* __restrict__ in,
+                                        const h16_t* __restrict__ addend,
+                                        h16_t* __restrict__ out, int N, int H, int W, int C,
                                         int shift, int ips, int aps, int ops) {
   const int Ho = H << shift, Wo = W << shift, C8 = C >> 3;
   const long long total = (long long)N * Ho * Wo * C8;
@@ -218,7 +218,7 @@ int launch_upsample_nearest(const void* in, const void* addend, void* out, int N
                   "upsample_nearest: C and strides must be multiples of 8, shift in 0..4");
   const long long total = ((long long)N * (H << shift) * (W << shift)) * (C >> 3);
   hipLaunchKernelGGL(upsample_nearest_kernel, dim3(grid_for(total)), dim3(256), 0, s,
-                     (const bf16_t*)in, (const bf16_t*)addend, (bf16_t*)out, N, H, W, C, shift, ips,
+                     (const h16_t*)in, (const h16_t*)addend, (h16_t*)out, N, H, W, C, shift, ips,
                      aps, ops);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
@@ -227,7 +227,7 @@ int launch_upsample_nearest(const void* in, const void* addend, void* out, int N
 // ---------------------------------------------------------------------------------
 // bilinear x2, half-pixel centres: src = (dst + 0.5)/2 - 0.5 clamped to [0, n-1]
 // ---------------------------------------------------------------------------------
-__global__ void upsample_bilinear2x_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+__global__ void upsample_bilinear2x_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out,
                                            int N, int H, int W, int C, int ips, int ops) {
   const int Ho = 2 * H, Wo = 2 * W, C8 = C >> 3;
   const long long total = (long long)N * Ho * Wo * C8;
@@ -244,7 +244,7 @@ __global__ void upsample_bilinear2x_kernel(const bf16_t* __restrict__ in, bf16_t
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
     const float fy = sy - y0, fx = sx - x0;
-    const bf16_t* base = in + (long long)n * H * W * ips + c8 * 8;
+    const h16_t* base = in + (long long)n * H * W * ips + c8 * 8;
     float a[8], b[8], c[8], d[8], o[8];
     unpack8(a, *reinterpret_cast<const uint4*>(base + ((long long)y0 * W + x0) * ips));
     unpack8(b, *reinterpret_cast<const uint4*>(base + ((long long)y0 * W + x1) * ips));
@@ -268,7 +268,7 @@ int launch_upsample_bilinear2x(const void* in, void* out, int N, int H, int W, i
                   "upsample_bilinear2x: C and strides must be multiples of 8");
   const long long total = (long long)N * 4 * H * W * (C >> 3);
   hipLaunchKernelGGL(upsample_bilinear2x_kernel, dim3(grid_for(total)), dim3(256), 0, s,
-                     (const bf16_t*)in, (bf16_t*)out, N, H, W, C, ips, ops);
+                     (const h16_t*)in, (h16_t*)out, N, H, W, C, ips, ops);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
 }
@@ -276,7 +276,7 @@ int launch_upsample_bilinear2x(const void* in, void* out, int N, int H, int W, i
 // ---------------------------------------------------------------------------------
 // y = relu(x*scale + shift)
 // ---------------------------------------------------------------------------------
-__global__ void scale_shift_relu_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+__global__ void scale_shift_relu_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out,
                                         const float* __restrict__ scale,
                                         const float* __restrict__ shift, long long pixels, int C,
                                         int ips, int ops) {
@@ -300,7 +300,7 @@ int launch_scale_shift_relu(const void* in, void* out, const float* scale, const
   MISEG_CHECK_ARG(pixels > 0 && C > 0 && (C & 7) == 0 && (ips & 7) == 0 && (ops & 7) == 0,
                   "scale_shift_relu: C and strides must be multiples of 8");
   hipLaunchKernelGGL(scale_shift_relu_kernel, dim3(grid_for(pixels * (C >> 3))), dim3(256), 0, s,
-                     (const bf16_t*)in, (bf16_t*)out, scale, shift, pixels, C, ips, ops);
+                     (const h16_t*)in, (h16_t*)out, scale, shift, pixels, C, ips, ops);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
 }
@@ -421,4 +421,4 @@ int launch_loss_sums_focal(const float* gt, const float* pr, double* sums, long 
   return launch_loss_sums_t<true>(gt, pr, sums, pixels, C, alpha, gamma, s);
 }
 
-}  // namespace miseg
+}  // namespace MISEG_KNS

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("MISEG_LIB") or os.path.join(_HERE, "libmiseg.so")   #
 OK = 0
 E_INVALID_ARG, E_UNSUPPORTED_SHAPE, E_HIP, E_NO_DEVICE = -1, -2, -3, -4
 DT_BF16, DT_F32 = 0, 1
+FMT_BF16, FMT_F16 = 0, 1      # 16-bit storage format of activations and weights (miseg_conv_desc.fmt)
 ACT_NONE, ACT_RELU, ACT_SOFTMAX, ACT_SIGMOID = 0, 1, 2, 3
 LOSS_CCE, LOSS_DICE, LOSS_FOCAL = 1, 2, 4
 
@@ -40,6 +41,7 @@ class ConvDesc(C.Structure):
         ("transposed", C.c_int32), ("temperature", C.c_float), ("collapse_value", C.c_int32),
         ("tile_hint", C.c_int32),
         ("stats", C.c_void_p), ("stats_replicas", C.c_int32), ("stats_stride", C.c_int32),
+        ("fmt", C.c_int32),
     ]
 
 
@@ -72,6 +74,12 @@ SIGNATURES = {
     "miseg_upsample_nearest_fwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_upsample_bilinear2x_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_scale_shift_relu_fwd": (C.c_int, [_VP, _VP, _FP, _FP, _I64, _I32, _I32, _I32, _VP]),
+    "miseg_prep_input_f16": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
+    "miseg_maxpool3x3s2_fwd_f16": (C.c_int, [_VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_avgpool2x2_fwd_f16": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_upsample_nearest_fwd_f16": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_upsample_bilinear2x_fwd_f16": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_scale_shift_relu_fwd_f16": (C.c_int, [_VP, _VP, _FP, _FP, _I64, _I32, _I32, _I32, _VP]),
     "miseg_collapse_u8": (C.c_int, [_FP, _VP, _I64, _I32, _I32, _VP]),
     "miseg_loss_sums": (C.c_int, [_FP, _FP, _VP, _I64, _I32, _VP]),
     "miseg_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), _VP]),
@@ -109,6 +117,7 @@ SIGNATURES = {
     "miseg_plan_create": (_VP, []),
     "miseg_plan_destroy": (None, [_VP]),
     "miseg_plan_num_ops": (C.c_int, [_VP]),
+    "miseg_plan_set_format": (C.c_int, [_VP, _I32]),
     "miseg_plan_add_conv": (C.c_int, [_VP, C.POINTER(ConvDesc)]),
     "miseg_plan_add_conv_c32_head": (C.c_int, [_VP, C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "miseg_plan_add_prep_input": (C.c_int, [_VP, _FP, _VP, _FP, _FP, _I32, _I32, _I32]),

@@ -2,11 +2,19 @@
 (oracle/nets.py on the torch back-end, fp32) on seeded random-init weights with
 randomised BatchNorm statistics.
 
-Bars (BASELINE.json north_star): probabilities within a stated tolerance (bf16
-activations: 3e-2 absolute), strict-argmax masks agreeing on >= 99.9 % of
-pixels where the oracle's top-2 margin exceeds the tolerance and >= 99 % overall
-(random-init networks put a few per cent of the pixels within bf16 noise of a tie),
-Dice (f1-score) and IoU against a common ground truth within 1e-3 of the oracle's.
+Bars (BASELINE.json north_star): probabilities within a stated tolerance, strict-argmax
+masks agreeing on >= 99.9 % of pixels, Dice (f1-score) and IoU against a common ground
+truth within 1e-3 of the oracle's.
+
+Two storage formats (Engine(storage=...)), two sets of bars:
+  fp16 (the inference default; 11 significand bits): probabilities within 1e-2; masks agree on
+    >= 99.9 % of ALL pixels at the headline size (test_headline_resnet34_unet_1920x2560, no
+    rescaling of anything); the small test images hold 4-6 thousand pixels, where 0.1 % is a
+    handful of near-ties, so there the bar is >= 99.9 % of the pixels whose top-2 margin exceeds the
+    tolerance and >= 99.5 % overall;
+  bf16 (the training format; 8 bits): probabilities within 3e-2, >= 99.9 % where the margin
+    exceeds 3e-2, >= 99 % overall (99.43 % at the headline size: every one of the ~90 stored
+    tensors of the network contributes about equally, see oracle/attribution.py).
 """
 import numpy as np
 import pytest
@@ -36,9 +44,64 @@ def make_inputs(n, h, w, seed=1234):
     return np.stack([post.normalize_image(i) for i in img])
 
 
+TOL = {"fp16": (1e-2, 0.995), "bf16": (3e-2, 0.99)}     # storage -> (probability tolerance, overall agreement)
+
+
 @pytest.mark.parametrize("enc,dec,hw,n,classes", CONFIGS)
 def test_engine_vs_oracle(enc, dec, hw, n, classes):
     check_engine(enc, dec, hw, n, classes)
+
+
+@pytest.mark.parametrize("enc,dec,hw,n,classes", [CONFIGS[0], CONFIGS[1], CONFIGS[3], CONFIGS[4]])
+def test_engine_vs_oracle_bf16_storage(enc, dec, hw, n, classes):
+    check_engine(enc, dec, hw, n, classes, storage="bf16")
+
+
+def headline_agreement(storage, h=1920, w=2560, want=None, x=None, weights=None):
+    """ResNet-34 U-Net, 3 classes, h x w x 3 (BASELINE config 2), seeded random-init weights with
+    randomised BatchNorm statistics, nothing rescaled.  Returns (share of pixels whose mask equals
+    the fp32 oracle's, |dF1|, |dIoU|, oracle probabilities) for the engine on `storage`."""
+    import miseg_amd
+    from miseg_amd import engine, netspec
+    from oracle import nets, ops_torch, post, losses
+    enc, dec, classes = "resnet34", "U-Net", 3
+    if weights is None:
+        weights = nets.init_weights(nets.build_spec(enc, dec, classes), seed=7, randomize_bn=True)
+    if x is None:
+        x = make_inputs(1, h, w)
+    if want is None:
+        with torch.no_grad():
+            want = ops_torch.to_numpy(nets.forward(ops_torch, enc, dec, weights, x))
+    g = netspec.build_graph(enc, dec, (h, w, 3), classes)
+    eng = engine.Engine(g, weights, batch=1, storage=storage)
+    got = eng.forward(torch.from_numpy(x).cuda()).cpu().numpy()
+    m_got = eng.mask.cpu().numpy()
+    del eng
+    torch.cuda.empty_cache()
+    m_want = np.stack([post.collapse_probabilities(p.copy()) for p in want])
+    agree = float((m_got == m_want).all(axis=-1).mean())
+    rng = np.random.default_rng(5)
+    ids = np.repeat(np.repeat(rng.integers(0, classes, (1, h // 64, w // 64)), 64, 1), 64, 2)
+    gt = np.stack([post.one_hot_encode(i[..., None], classes) for i in ids])
+    df1 = abs(losses.f1_score(gt, got) - losses.f1_score(gt, want))
+    diou = abs(losses.iou_score(gt, got) - losses.iou_score(gt, want))
+    return agree, df1, diou, want, x, weights, float(np.abs(got - want).max())
+
+
+def test_headline_resnet34_unet_1920x2560():
+    """The headline configuration against the fp32 oracle, at the north-star bar as written:
+    strict-argmax masks agree on >= 99.9 % of all pixels, Dice and IoU within 1e-3 (fp16 storage,
+    the engine's default).  The same run on bf16 storage is recorded beside it with the bar it
+    reaches (>= 99.3 %)."""
+    agree, df1, diou, want, x, weights, dp = headline_agreement("fp16")
+    print("fp16 storage: masks agree on %.4f %%, |dF1| %.2e, |dIoU| %.2e, max|dp| %.4f" % (100 * agree, df1, diou, dp))
+    assert agree >= 0.999, agree
+    assert df1 < 1e-3 and diou < 1e-3
+    assert dp < 3e-2
+    agree_b, df1_b, diou_b, _, _, _, dp_b = headline_agreement("bf16", want=want, x=x, weights=weights)
+    print("bf16 storage: masks agree on %.4f %%, |dF1| %.2e, |dIoU| %.2e, max|dp| %.4f" % (100 * agree_b, df1_b, diou_b, dp_b))
+    assert agree_b >= 0.993, agree_b
+    assert df1_b < 1e-3 and diou_b < 1e-3
 
 
 def test_engine_bf16_residual_stream():
@@ -49,6 +112,7 @@ def test_engine_bf16_residual_stream():
 
 
 def check_engine(enc, dec, hw, n, classes, **engine_options):
+    tol, overall = TOL[engine_options.get("storage", "fp16")]
     import miseg_amd
     from miseg_amd import engine, netspec
     from oracle import nets, ops_torch, post, losses
@@ -80,16 +144,16 @@ def check_engine(enc, dec, hw, n, classes, **engine_options):
             b = taps[name]
             err = np.abs(a - b).max() / (np.abs(b).max() + 1e-6)
             assert err < 0.05, "%s: relative max error %.4f" % (name, err)
-    assert np.abs(got - want).max() < 3e-2
+    assert np.abs(got - want).max() < tol
     if classes > 1:
         m_got = eng.mask.cpu().numpy()
         m_want = np.stack([post.collapse_probabilities(p) for p in want])
         np.testing.assert_array_equal(m_got, np.stack([post.collapse_probabilities(p) for p in got]))
         agree = (m_got == m_want).all(axis=-1)
         top2 = np.sort(want, axis=-1)
-        clear = (top2[..., -1] - top2[..., -2]) > 3e-2
+        clear = (top2[..., -1] - top2[..., -2]) > tol
         assert agree[clear].mean() >= 0.999
-        assert agree.mean() >= 0.99
+        assert agree.mean() >= overall
         # Dice / loss against a synthetic blocky ground truth: both models must score alike
         rng = np.random.default_rng(5)
         ids = np.repeat(np.repeat(rng.integers(0, classes, (n, h // 16, w // 16)), 16, 1), 16, 2)

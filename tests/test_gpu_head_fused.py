@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_gpu_kernels import bf16_round, dev_bf16, dev_f32, env  # noqa: F401
+from test_gpu_kernels import bf16_round, dev_bf16, dev_f32, env, storage, new_desc, h16  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -18,14 +18,14 @@ def descs(L, dev, x, wb, sb, tb, wh, bias, classes, act, temperature, keep):
     xin = dev_bf16(x, dev)
     wbt = dev_bf16(wb.transpose(3, 0, 1, 2), dev)
     wht = dev_bf16(wh.transpose(3, 0, 1, 2), dev)
-    mid = torch.zeros((n, h, w, 32), dtype=torch.bfloat16, device=dev)
+    mid = torch.zeros((n, h, w, 32), dtype=h16(), device=dev)
     probs = torch.zeros((n, h, w, classes), dtype=torch.float32, device=dev)
     mask = torch.zeros((n, h, w, classes), dtype=torch.uint8, device=dev)
     s, t, b = dev_f32(sb, dev), dev_f32(tb, dev), dev_f32(bias, dev)
     keep += [xin, wbt, wht, mid, probs, mask, s, t, b]
 
     def base(cout):
-        d = L.ConvDesc()
+        d = new_desc(L)
         d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, 32, h, w, cout
         d.KH = d.KW = 3
         d.stride_y = d.stride_x = d.pad_y = d.pad_x = 1
