@@ -4,10 +4,15 @@ autograd and the CPU oracle (oracle/train.py restates model_train.py:284-329).
 Tolerances.  Activations, activation gradients and convolution weights are stored in bf16, so
  * layer by layer, on identical inputs: forward outputs and data gradients agree with fp32 torch
    to bf16 rounding (relative L2 <= 6e-3), parameter gradients (fp32 accumulation) to 2e-3;
- * end to end against the fp32 oracle only loss and head gradients are tight: a batch-normalised
-   network in training mode amplifies a 1e-6 input perturbation of a bf16-storage run to a few
-   percent at the logits (measured on the oracle's own bf16 emulation), so deep-layer gradients of
-   two correct bf16 runs differ by tens of percent.  The layer-wise test is the correctness gate.
+ * end to end against the fp32 oracle only loss and head gradients are tight.  The random-init,
+   batch-normalised network in training mode is ill-conditioned as a function: in the FP32 oracle
+   itself a 1e-6 perturbation of the input moves the encoder's parameter gradients by 2-3 %
+   (amplification ~10^4), so ANY run that stores activations in bf16 (relative rounding 4e-3) lands
+   tens of per cent away there: the oracle's own bf16 emulation (oracle/ops_bf16.py, same rounding
+   points as the device path) differs from the fp32 oracle by 0.1 (decoder_stage4b) to 0.69 (encoder).
+   The end-to-end gate is therefore relative to that emulation: per parameter tensor, the device
+   path may be no further from the fp32 oracle than 1.5x the emulation's own distance (+ 1e-2).
+   The layer-wise test is the absolute correctness gate.
 PARITY UNPINNED: the reference holds no training fixtures; see oracle/train.py.
 """
 import os
@@ -27,6 +32,8 @@ CONFIGS = [
     ("densenet121", "U-Net", 64, 64, 2),
     ("densenet121", "Linknet", 64, 96, 1),
     ("densenet121", "FPN", 64, 64, 1),
+    ("densenet169", "FPN", 64, 64, 1),          # BASELINE config 5's network
+    ("densenet169", "Linknet", 64, 64, 1),      # the reference's preferred model
 ]
 
 
@@ -81,6 +88,41 @@ def test_loss_and_head_gradients_vs_oracle(pkg):
                                      st["mean"][:m.size].cpu().numpy(), st["var"][:m.size].cpu().numpy(), count)
         assert np.allclose(tr.moving[name][0].cpu().numpy(), mm, rtol=1e-4, atol=1e-5)
         assert np.allclose(tr.moving[name][1].cpu().numpy(), mv, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("encoder,decoder,h,w,n", [("resnet18", "U-Net", 128, 192, 2), ("densenet121", "FPN", 64, 64, 2)])
+def test_gradients_no_further_from_fp32_than_the_bf16_emulation(pkg, encoder, decoder, h, w, n):
+    """End to end: every parameter gradient of one HIP training step against the fp32 oracle,
+    with the oracle's bf16-storage emulation as the yardstick (see the module docstring)."""
+    import train_selfcheck as sc
+    from oracle import train, ops_bf16
+    tr, weights, x, gt = sc.run(encoder, decoder, h, w, n)
+    gw = sc.grads_as_weights(tr)
+    loss32, _, g32, _ = train.loss_and_grads(encoder, decoder, weights, x, gt)
+    loss16, _, g16, _ = train.loss_and_grads(encoder, decoder, weights, x, gt, ops=ops_bf16)
+    s = tr.loss_sums.cpu().numpy().reshape(4, 3)
+    tp, spr, sgt, ce = s
+    mine = -ce.sum() / gt.size + 1.0 - np.mean((2 * tp + 1e-5) / (sgt + spr + 1e-5))
+    assert abs(mine - loss32) <= max(2 * abs(loss16 - loss32), 1e-3 * abs(loss32)), (mine, loss32, loss16)
+    bad, ratios = [], []
+    for l in g32:
+        for k in g32[l]:
+            ref = g32[l][k]
+            nr = np.linalg.norm(ref)
+            if nr == 0:
+                continue
+            e_dev = np.linalg.norm(gw[l][k] - ref) / nr
+            e_emu = np.linalg.norm(g16[l][k] - ref) / nr
+            ratios.append(e_dev / max(e_emu, 1e-3))
+            if e_dev > 1.5 * e_emu + 1e-2:
+                bad.append((l, k, float(e_dev), float(e_emu)))
+    assert not bad, bad[:10]
+    assert np.median(ratios) < 1.2, np.median(ratios)      # on the whole, as close as the emulation
+    a = np.concatenate([gw[l][k].ravel() for l in g32 for k in g32[l]])
+    b16 = np.concatenate([g16[l][k].ravel() for l in g32 for k in g32[l]])
+    b32 = np.concatenate([g32[l][k].ravel() for l in g32 for k in g32[l]])
+    cos = lambda u, v: float(u @ v / (np.linalg.norm(u) * np.linalg.norm(v)))
+    assert cos(a, b32) >= cos(b16, b32) - 0.03, (cos(a, b32), cos(b16, b32))
 
 
 def test_training_reduces_loss_like_the_oracle(pkg):
