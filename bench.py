@@ -59,9 +59,20 @@ def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
             el = time.perf_counter() - t0
             if el > budget_s * 0.5 or n_done >= 3:
                 break
+        # BASELINE config 1: the reference's own CPU-runnable case (predict.py --gpu -1, 512x512x3, batch 1)
+        x512 = synthetic_images(1, 512, 512, seed=97)
+        nets.forward(ops_torch, encoder, decoder, weights, x512)
+        t1 = time.perf_counter()
+        n512 = 0
+        while n512 < 10 and time.perf_counter() - t1 < 5.0:
+            nets.forward(ops_torch, encoder, decoder, weights, x512)
+            n512 += 1
+        el512 = time.perf_counter() - t1
     return {"value": n_done / el, "unit": "images/s", "cores": threads, "kind": "port",
             "sample": "%d forward pass(es) of 1 image %dx%dx3, oracle/nets.py on torch-CPU fp32 "
-                      "(TensorFlow reference not installable offline)" % (n_done, h, w)}
+                      "(TensorFlow reference not installable offline)" % (n_done, h, w),
+            "config1_512x512": {"value": n512 / el512, "unit": "images/s",
+                                "sample": "%d forward passes of 1 image 512x512x3, same network and cores" % n512}}
 
 
 def pmc_traffic(kernel, batch, h, w, encoder, decoder):
@@ -108,6 +119,7 @@ def training_leg(args, dev, rank, world, dist, h, w):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    roof = train_roofline(tr.profile_step(x, gt), 1e3 * elapsed / args.train_steps) if rank == 0 else None
     del tr, x, gt
     torch.cuda.empty_cache()
     return {"metric": "images/sec at 1920x2560x3 ResNet-18 U-Net training",
@@ -120,7 +132,51 @@ def training_leg(args, dev, rank, world, dist, h, w):
                                                          args.classes, args.train_batch),
                        "parallelism": "data parallel, bucketed RCCL all-reduce overlapped with backward"
                        if world > 1 else "single GPU"},
-            "peak_hbm_gib": peak}
+            "peak_hbm_gib": peak, "roofline": roof}
+
+
+def train_roofline(prof, ms_per_step):
+    """`roofline` of the training leg from one step timed launch by launch (HIP events on each
+    launch's own stream, Trainer.profile_step).  The dominant kernel is the one with the largest
+    summed duration; convolution kernels are priced against the bf16 MFMA peak with their
+    algorithmic FLOP (forward, data gradient and weight gradient: 2 x MAC each), the others against
+    the HBM peak with their algorithmic bytes (operands read once, results written once).
+    Weight gradients run on a second stream beside the data-gradient chain, so the launch durations
+    include that contention and their sum exceeds the step time."""
+    dom_name = max(prof, key=lambda k: prof[k]["ms"])
+    dom = prof[dom_name]
+    conv = [g for g in prof.values() if g["flops"] > 0]
+    conv_ms, conv_flops = sum(g["ms"] for g in conv), sum(g["flops"] for g in conv)
+    other = [g for g in prof.values() if g["flops"] == 0]
+    other_ms, other_bytes = sum(g["ms"] for g in other), sum(g["bytes"] for g in other)
+    total_bytes = sum(g["bytes"] for g in prof.values())
+    if dom["flops"] > 0:
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        head = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9}
+    else:
+        ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        head = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
+    head.update({
+        "kernel": dom_name, "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+        "timing": "HIP events around every launch of one step, on the launch's own stream", "traffic": None,
+        "all_conv_launches": {"achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
+                              "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                              "gflop_per_step": conv_flops / 1e9, "ms_per_step": conv_ms,
+                              "note": "forward + data-gradient + weight-gradient convolutions, summed launch durations"},
+        "bandwidth_bound_launches": {"achieved_gbs": other_bytes / (other_ms * 1e-3) / 1e9,
+                                     "frac": other_bytes / (other_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "gbytes_per_step": other_bytes / 1e9, "ms_per_step": other_ms},
+        "whole_step": {"algorithmic_gbytes": total_bytes / 1e9, "gflop": conv_flops / 1e9, "ms": ms_per_step,
+                       "hbm_frac": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "mfma_frac": conv_flops / (ms_per_step * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+        "kernels": {k: {"launches": g["launches"], "ms": round(g["ms"], 3),
+                        "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 1) if g["flops"] else None,
+                        "gbs": round(g["bytes"] / (g["ms"] * 1e-3) / 1e9, 1)}
+                    for k, g in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]},
+    })
+    return head
 
 
 def main():

@@ -144,6 +144,9 @@ typedef struct miseg_conv_desc {
 } miseg_conv_desc;
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);
+/* Name of the device kernel miseg_conv2d_fwd launches for `d` (as a profiler prints it, without the
+ * namespace), into buf: lets a caller attribute its own HIP-event timings to kernels. */
+int miseg_conv_kernel_name(const miseg_conv_desc* d, char* buf, int32_t buflen);
 
 /*
  * The tail of the U-Net the reference builds at utils/model.py:176-186, as one kernel:

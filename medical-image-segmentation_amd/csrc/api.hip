@@ -164,6 +164,12 @@ int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream) {
   return launch_conv(d, (hipStream_t)stream);
 }
 
+int miseg_conv_kernel_name(const miseg_conv_desc* d, char* buf, int32_t buflen) {
+  MISEG_CHECK_ARG(d && buf && buflen > 0, "conv_kernel_name: null argument");
+  conv_kernel_name(d, buf, buflen);
+  return MISEG_OK;
+}
+
 int miseg_conv_c32_head_fwd(const miseg_conv_desc* body, const miseg_conv_desc* head, void* stream) {
   MISEG_CHECK_ARG(body && head, "conv_c32_head: null descriptor");
   MISEG_CHECK_FMT(body->fmt);
@@ -502,7 +508,9 @@ int64_t miseg_plan_op_macs(const miseg_plan* p, int index) {
   const Op& o = p->ops[index];
   if (o.kind != OP_CONV && o.kind != OP_CONV_HEAD) return 0;
   const miseg_conv_desc& d = o.conv;
-  const int64_t per = (int64_t)d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin;
+  int64_t per = (int64_t)d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin;
+  // the 7x7x3 stem runs as 7x1 taps over 8 pixels x 4 channels (K = 224): count the layer's own 147
+  if (d.KH == 7 && d.KW == 1 && d.Cin == 32 && d.stride_y == 2) per = (int64_t)d.N * d.Ho * d.Wo * d.Cout * 147;
   if (o.kind == OP_CONV_HEAD) return per + (int64_t)d.N * d.Ho * d.Wo * o.conv2.Cout * 9 * o.conv2.Cin;
   return d.transposed ? 4 * per : per;
 }

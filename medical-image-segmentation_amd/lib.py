@@ -66,6 +66,7 @@ SIGNATURES = {
     "miseg_version": (C.c_int, []),
     "miseg_device_check": (C.c_int, []),
     "miseg_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _VP]),
+    "miseg_conv_kernel_name": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, _I32]),
     "miseg_conv_c32_head_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _VP]),
     "miseg_prep_input": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
     "miseg_prep_input_indicator": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),

@@ -280,16 +280,25 @@ class Model:
             if not isinstance(a, torch.Tensor):
                 a = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32)))
             return a.to(dev, torch.float32).contiguous()
-        x, y = prep(x), prep(y)
+        sums, pixels = self._train_step_async(prep(x), prep(y))
+        logs = self._logs_from_sums(sums.cpu().numpy(), pixels)
+        return logs if return_dict else list(logs.values())
+
+    def _train_step_async(self, x, y):
+        """One optimisation step without a host synchronisation: returns the step's per-class sums
+        as a DEVICE tensor (a copy: the trainer reuses its buffer) and the pixel count."""
         t = self._trainer(x.shape[0])
         t.lr = float(self.optimizer.learning_rate) if self.optimizer is not None else t.lr
         sums, pixels = t.train_step(x, y)
-        s = sums.cpu().numpy().reshape(-1, t.classes)
+        return sums.clone(), pixels
+
+    def _logs_from_sums(self, sums, pixels):
+        s = np.asarray(sums).reshape(-1, self.graph.classes)
         loss = self._loss_object()
         logs = OrderedDict([("loss", loss.from_sums(s, pixels))])
         for m in self.metrics:
             logs[getattr(m, "name", getattr(m, "__name__", str(m)))] = m.from_sums(s, pixels)
-        return logs if return_dict else list(logs.values())
+        return logs
 
     def sync_from_trainer(self, collective=True):
         """Copy the trained parameters (and moving statistics, averaged over ranks) back into
@@ -342,6 +351,7 @@ class Model:
             if it is None or y is not None:
                 it = iter(batches())
             totals, count, fresh = OrderedDict(), 0, False
+            pending = []        # (device sums, pixels) of the epoch's steps: read back once, at its end
             while steps_per_epoch is None or count < steps_per_epoch:
                 try:
                     bx, by = next(it)
@@ -352,12 +362,19 @@ class Model:
                         break
                     it, fresh = iter(batches()), True   # a finite dataset is simply walked again
                     continue
-                logs = self.train_on_batch(bx, by)
-                for k, v in logs.items():
-                    totals[k] = totals.get(k, 0.0) + v
+                dev = torch.device(self.device)
+                bx, by = (a if isinstance(a, torch.Tensor) else
+                          torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))) for a in (bx, by))
+                pending.append(self._train_step_async(bx.to(dev, torch.float32).contiguous(),
+                                                      by.to(dev, torch.float32).contiguous()))
                 count += 1
             if count == 0:
                 raise ValueError("fit() got an empty dataset")
+            # one device -> host transfer per epoch instead of a synchronisation per step
+            host = torch.stack([p[0] for p in pending]).cpu().numpy()
+            for row, (_, pixels) in zip(host, pending):
+                for k, v in self._logs_from_sums(row, pixels).items():
+                    totals[k] = totals.get(k, 0.0) + v
             logs = OrderedDict((k, v / count) for k, v in totals.items())
             self._reduce_logs(logs)
             self.sync_from_trainer()

@@ -83,7 +83,8 @@ class Trainer:
                  freeze_encoder=False):
         if not torch.cuda.is_available():
             raise L.MisegError("no GPU visible: the HIP training path has no CPU fallback")
-        self.lib = L.load()
+        from .profile import TimedLib
+        self.lib = TimedLib(L.load())      # transparent unless profile_step() switches it on
         self.dev = torch.device(device)
         torch.cuda.set_device(self.dev)
         # Weight gradients are off the critical path of the backward pass (nothing downstream reads
@@ -367,7 +368,21 @@ class Trainer:
         d.temperature = temperature
         if stats is not None:
             d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), STAT_REPLICAS, _c32(cout)
+        self._note_conv(d, x, probs is not None, residual is not None)
         L.check(self.lib.miseg_conv2d_fwd(C.byref(d), self.stream()))
+
+    def _note_conv(self, d, x, f32_out, has_res):
+        """Algorithmic work of a convolution call, for profile_step()."""
+        if not self.lib.on:
+            return
+        buf = C.create_string_buffer(128)
+        L.check(self.lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+        taps = d.KH * d.KW * (4 if d.transposed else 1)
+        opix = d.N * d.Ho * d.Wo * (4 if d.transposed == 1 else 1)
+        macs = d.N * d.Ho * d.Wo * d.Cout * taps * d.Cin
+        nbytes = x.n * x.h * x.w * d.Cin * 2 + d.Cout * taps * d.Cin * 2 + \
+            opix * d.Cout * ((4 if f32_out else 2) + (2 if has_res else 0))
+        self.lib.note(buf.value.decode(), macs, nbytes)
 
     def _stats_for(self, name, cout):
         """The statistics buffer of the BatchNormalization that is the only consumer of convolution
@@ -397,6 +412,9 @@ class Trainer:
         d.Cin, d.Ho, d.Wo, d.Cout = cin, ho, wo, cout
         d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
         d.dy_pix, d.dy_row, d.dy_img = dy_strides
+        halo = sx == 1 and sy == 1 and kh == kw and kh <= 3 and cin % 32 == 0 and 0 <= py < kh and 0 <= px < kw
+        self.lib.note("wgrad_halo_kernel" if halo else "conv_wgrad_kernel", d.N * ho * wo * cout * kh * kw * cin,
+                      d.N * d.H * d.W * cin * 2 + d.N * ho * wo * cout * 2 + cout * kh * kw * cin * 4)
         if self.side is None:
             L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.stream()))
             return
@@ -659,6 +677,11 @@ class Trainer:
         stats = self._stats_for(l.name, 64)
         if stats is not None:
             d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), STAT_REPLICAS, 64
+        if self.lib.on:
+            buf = C.create_string_buffer(128)
+            L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+            pix = n * (h // 2) * (w // 2)
+            self.lib.note(buf.value.decode(), pix * 64 * 147, n * (h + 6) * (w + 8) * 8 + pix * 128)
         L.check(lib.miseg_conv2d_fwd(C.byref(d), st))
         self.acts[l.name] = out
         self.saved[l.name] = (padded, src)
@@ -974,6 +997,17 @@ class Trainer:
             for t in pair:
                 t.copy_(flat[off:off + t.numel()])
                 off += t.numel()
+
+    def profile_step(self, x, gt):
+        """One training step with every kernel launch timed by HIP events on its own stream.
+        Returns {kernel: {"launches", "ms", "flops", "bytes"}} (see profile.TimedLib)."""
+        self.lib.records = []
+        self.lib.on = True
+        try:
+            self.train_step(x, gt)
+        finally:
+            self.lib.on = False
+        return self.lib.summary()
 
     def train_step(self, x, gt):
         """One optimisation step on a local batch.  Returns (sums, pixels) of the forward pass for
