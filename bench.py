@@ -203,8 +203,9 @@ def main():
     ap.add_argument("--storage", default="fp16", choices=["fp16", "bf16"],
                     help="16-bit storage format of activations and weights (same kernels, rate and bytes; fp16 is "
                          "the engine's default because its masks match the fp32 reference on >= 99.9 %% of pixels)")
-    ap.add_argument("--residual-bf16", action="store_true",
-                    help="keep the ResNet residual stream in bf16 (Engine(residual_bf16=True)); not the default")
+    ap.add_argument("--residual", default="auto", choices=["auto", "16", "32"],
+                    help="ResNet residual stream: 16-bit storage format or fp32 (auto: 16-bit with fp16 storage, "
+                         "fp32 with bf16 storage; see Engine)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -233,7 +234,7 @@ def main():
     weights = build_weights(graph)
     # Images are independent: each plan owns its buffers and runs on its own stream, so the tail of
     # one plan's kernel overlaps the head of another's.
-    engs = [engine.Engine(graph, weights, batch=args.batch, device=str(dev), residual_bf16=args.residual_bf16,
+    engs = [engine.Engine(graph, weights, batch=args.batch, device=str(dev), residual_bf16={"auto": None, "16": True, "32": False}[args.residual],
                           storage=args.storage)
             for _ in range(args.streams)]
     streams = [torch.cuda.Stream(dev) for _ in range(args.streams)]
@@ -329,7 +330,8 @@ def main():
             "config": {"workload": "%s %s inference %dx%dx3, %d classes, random-init weights, "
                                    "%d images per GPU per step (%d concurrent plans of %d images)%s" %
                                    (args.encoder, args.decoder, h, w, args.classes, per_step, args.streams,
-                                    args.batch, ", bf16 residual stream" if args.residual_bf16 else ""),
+                                    args.batch, ", %s storage, %s residual stream" % (
+                                        args.storage, "16-bit" if eng.residual_bf16 else "fp32")),
                        "images_per_step_per_gpu": per_step,
                        "parallelism": "independent images per GPU, no collective"},
             "roofline": {

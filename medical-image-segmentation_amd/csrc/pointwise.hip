@@ -80,40 +80,69 @@ __device__ __forceinline__ uint4 pack8(const float (&m)[8]) {
                     pack_h16x2(m[6], m[7]));
 }
 
+// One thread: 8 channels of MP_ROWS vertically adjacent output pixels.  An input row between two
+// output rows belongs to both windows; walking down the column keeps it in registers (the running
+// maximum of each input row over its three columns), so a thread fetches 2 * MP_ROWS + 1 input rows
+// instead of 3 * MP_ROWS, and neighbouring threads of a wave cover neighbouring columns.
+constexpr int MP_ROWS = 4;
 __global__ void maxpool3x3s2_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out,
                                     const float* __restrict__ scale,
                                     const float* __restrict__ shift, int N, int H, int W, int C,
                                     int ips, int ops) {
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int C8 = C >> 3;
-  const long long total = (long long)N * Ho * Wo * C8;
+  const int Hg = (Ho + MP_ROWS - 1) / MP_ROWS;
+  const long long total = (long long)N * Hg * Wo * C8;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c8 = (int)(i % C8);
     long long r = i / C8;
     const int ox = (int)(r % Wo);
     r /= Wo;
-    const int oy = (int)(r % Ho);
-    const int n = (int)(r / Ho);
-    float m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int og = (int)(r % Hg);
+    const int n = (int)(r / Hg);
+    const int oy0 = og * MP_ROWS;
+    float sc[8], sh[8];
+    if (scale) {
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int y = 2 * oy - 1 + dy;
-      if ((unsigned)y >= (unsigned)H) continue;
+      for (int j = 0; j < 8; ++j) {
+        sc[j] = scale[c8 * 8 + j];
+        sh[j] = shift[c8 * 8 + j];
+      }
+    }
+    // maximum over the three columns of input row y (zeros outside the image: inputs are >= 0)
+    auto row_max = [&](int y, float (&m)[8]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = 0.f;
+      if ((unsigned)y >= (unsigned)H) return;
+      const h16_t* rowp = in + (((long long)n * H + y) * W) * ips + c8 * 8;
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const int x = 2 * ox - 1 + dx;
         if ((unsigned)x >= (unsigned)W) continue;
-        const uint4 v = *reinterpret_cast<const uint4*>(
-            in + (((long long)n * H + y) * W + x) * ips + c8 * 8);
-        max8(m, v);
+        max8(m, *reinterpret_cast<const uint4*>(rowp + (long long)x * ips));
       }
-    }
-    if (scale) {
+    };
+    float carry[8];                       // input row 2*oy - 1 of the next output row
+    row_max(2 * oy0 - 1, carry);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j] * scale[c8 * 8 + j] + shift[c8 * 8 + j], 0.f);
+    for (int k = 0; k < MP_ROWS; ++k) {
+      const int oy = oy0 + k;
+      if (oy >= Ho) break;
+      float a[8], b[8], m[8];
+      row_max(2 * oy, a);
+      row_max(2 * oy + 1, b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        m[j] = fmaxf(fmaxf(carry[j], a[j]), b[j]);
+        carry[j] = b[j];
+      }
+      if (scale) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j] * sc[j] + sh[j], 0.f);
+      }
+      *reinterpret_cast<uint4*>(out + (((long long)n * Ho + oy) * Wo + ox) * ops + c8 * 8) = pack8(m);
     }
-    *reinterpret_cast<uint4*>(out + (((long long)n * Ho + oy) * Wo + ox) * ops + c8 * 8) = pack8(m);
   }
 }
 
@@ -125,7 +154,7 @@ int launch_maxpool3x3s2(const void* in, void* out, const float* scale, const flo
                       (ops & 7) == 0 && ips >= C && ops >= C,
                   "maxpool: C and strides must be multiples of 8");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  const long long total = (long long)N * Ho * Wo * (C >> 3);
+  const long long total = (long long)N * ((Ho + MP_ROWS - 1) / MP_ROWS) * Wo * (C >> 3);
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const h16_t*)in,
                      (h16_t*)out, scale, shift, N, H, W, C, ips, ops);
   MISEG_CHECK_HIP(hipGetLastError());

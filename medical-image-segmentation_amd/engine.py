@@ -66,7 +66,7 @@ def _ceil32(c):
 
 class Engine:
     def __init__(self, graph, weights, batch=1, device="cuda:0", collapse_value=127,
-                 keep_logits=False, fuse_tail=True, residual_bf16=False, storage="fp16"):
+                 keep_logits=False, fuse_tail=True, residual_bf16=None, storage="fp16"):
         """graph: netspec.Graph; weights: {layer: {weight_name: np.ndarray fp32}}."""
         if not torch.cuda.is_available():
             raise L.MisegError("no GPU visible: the HIP engine has no CPU fallback")
@@ -88,10 +88,13 @@ class Engine:
         self.tdtype = torch.float16 if storage == "fp16" else torch.bfloat16
         # U-Net: decoder_stage4b and final_conv as one kernel (the tensor between them stays on chip)
         self.fuse_tail = fuse_tail
-        # ResNet residual stream in bf16 instead of fp32: the convolutions that close a residual unit
-        # move 4 instead of 10 bytes per element (+3.6 % images/s at 1920x2560) for 0.03 points of
-        # mask agreement with the fp32 oracle (99.43 % -> 99.39 %); off by default
-        self.residual_bf16 = residual_bf16
+        # ResNet residual stream in the 16-bit storage format instead of fp32: the convolutions that
+        # close a residual unit move 4 instead of 10 bytes per element (+4.7 % images/s at
+        # 1920x2560).  Measured mask agreement with the fp32 oracle at 1920x2560: fp16 storage
+        # 99.932 % -> 99.928 % (still above the 99.9 % bar: on by default there); bf16 storage
+        # 99.43 % -> 99.40 % (already below the bar: off by default, parity first).
+        # None = that default; True / False force it.
+        self.residual_bf16 = (storage == "fp16") if residual_bf16 is None else bool(residual_bf16)
         self.h, self.wd, _ = graph.input_shape
         self.classes = graph.classes
         self.collapse_value = collapse_value

@@ -104,11 +104,12 @@ def test_headline_resnet34_unet_1920x2560():
     assert df1_b < 1e-3 and diou_b < 1e-3
 
 
-def test_engine_bf16_residual_stream():
-    """Engine(residual_bf16=True) keeps the ResNet residual stream in bf16 (faster, off by
-    default); it must clear the same bars."""
-    check_engine("resnet34", "U-Net", (96, 64), 1, 3, residual_bf16=True)
-    check_engine("resnet18", "Linknet", (64, 64), 1, 3, residual_bf16=True)
+def test_engine_residual_stream_options():
+    """The ResNet residual stream is 16-bit by default on fp16 storage and fp32 on bf16 storage
+    (Engine(residual_bf16=None)); the other two combinations must clear their format's bars too."""
+    check_engine("resnet34", "U-Net", (96, 64), 1, 3, residual_bf16=False)
+    check_engine("resnet34", "U-Net", (96, 64), 1, 3, residual_bf16=True, storage="bf16")
+    check_engine("resnet18", "Linknet", (64, 64), 1, 3, residual_bf16=True, storage="bf16")
 
 
 def check_engine(enc, dec, hw, n, classes, **engine_options):
