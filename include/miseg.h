@@ -161,6 +161,22 @@ int miseg_conv_kernel_name(const miseg_conv_desc* d, char* buf, int32_t buflen);
 int miseg_conv_c32_head_fwd(const miseg_conv_desc* body, const miseg_conv_desc* head, void* stream);
 
 /*
+ * One layer of a DenseNet block as one kernel (keras_applications `conv_block`, the encoder the
+ * reference selects at utils/model.py:188-211): <name>_0_bn + _0_relu applied to the first Cin
+ * channels of the concatenation buffer, <name>_1_conv (1x1, Cin -> 128), _1_bn + _1_relu,
+ * <name>_2_conv (3x3, 128 -> 32, zero padding 1), whose 32 output channels are appended to the
+ * same buffer (_concat).  `c1` describes the 1x1 convolution as for miseg_conv2d_fwd: in and its
+ * strides, Cin % 32 == 0 (at most 1792 with bf16 storage), weight [128][Cin], in_scale / in_shift
+ * (the first BatchNorm), scale / shift (the second), act = MISEG_ACT_RELU; its out pointers are
+ * ignored.  `c2` describes the 3x3 convolution: weight [32][3][3][128], 16-bit out with its
+ * strides (usually the same buffer at channel offset Cin), optional scale / shift, no activation.
+ * The 128-channel tensor between the two stays on chip.  Same results as the two
+ * miseg_conv2d_fwd calls up to the rounding of the input BatchNorm (evaluated in the storage
+ * format's own arithmetic when that is fp16).
+ */
+int miseg_dense_layer_fwd(const miseg_conv_desc* c1, const miseg_conv_desc* c2, void* stream);
+
+/*
  * Input contract of the encoders: fp32 NHWC image with 3 channels ->
  * bf16 [N][H+6][W+8][4] with the image at rows 3.., columns 3.., channel 3 and
  * the border zero; value = x*scale[c] + shift[c] (ResNet `bn_data`, a
@@ -455,6 +471,7 @@ int miseg_plan_num_ops(const miseg_plan* p);
 int miseg_plan_set_format(miseg_plan* p, int32_t fmt);
 int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d);
 int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, const miseg_conv_desc* head);
+int miseg_plan_add_dense_layer(miseg_plan* p, const miseg_conv_desc* c1, const miseg_conv_desc* c2);
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
                               const float* shift, int32_t N, int32_t H, int32_t W);
 int miseg_plan_add_maxpool3x3s2(miseg_plan* p, const void* in, void* out, const float* scale,

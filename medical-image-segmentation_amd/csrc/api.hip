@@ -65,12 +65,12 @@ namespace miseg_f16 {
 }
 namespace miseg {
 
-enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD };
+enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD, OP_DENSE };
 
 struct Op {
   OpKind kind;
   miseg_conv_desc conv;
-  miseg_conv_desc conv2;   // OP_CONV_HEAD: the head convolution
+  miseg_conv_desc conv2;   // OP_CONV_HEAD: the head convolution; OP_DENSE: the 3x3 convolution
   const void* in;
   const void* in2;
   void* out;
@@ -85,6 +85,7 @@ static int run_op_f16(const Op& o, hipStream_t s) {
   switch (o.kind) {
     case OP_CONV: return F::launch_conv(&o.conv, s);
     case OP_CONV_HEAD: return F::launch_conv_c32_head(&o.conv, &o.conv2, s);
+    case OP_DENSE: return F::launch_dense_layer(&o.conv, &o.conv2, s);
     case OP_PREP: return F::launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
     case OP_MAXPOOL:
       return F::launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
@@ -105,6 +106,7 @@ static int run_op(const Op& o, hipStream_t s, int fmt) {
   switch (o.kind) {
     case OP_CONV: return launch_conv(&o.conv, s);
     case OP_CONV_HEAD: return launch_conv_c32_head(&o.conv, &o.conv2, s);
+    case OP_DENSE: return launch_dense_layer(&o.conv, &o.conv2, s);
     case OP_PREP: return launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
@@ -176,6 +178,14 @@ int miseg_conv_c32_head_fwd(const miseg_conv_desc* body, const miseg_conv_desc* 
   MISEG_CHECK_ARG(body->fmt == head->fmt, "conv_c32_head: body and head must use one storage format");
   if (body->fmt == MISEG_FMT_F16) return miseg_f16::launch_conv_c32_head(body, head, (hipStream_t)stream);
   return launch_conv_c32_head(body, head, (hipStream_t)stream);
+}
+
+int miseg_dense_layer_fwd(const miseg_conv_desc* c1, const miseg_conv_desc* c2, void* stream) {
+  MISEG_CHECK_ARG(c1 && c2, "dense_layer: null descriptor");
+  MISEG_CHECK_FMT(c1->fmt);
+  MISEG_CHECK_ARG(c1->fmt == c2->fmt, "dense_layer: the two convolutions must use one storage format");
+  if (c1->fmt == MISEG_FMT_F16) return miseg_f16::launch_dense_layer(c1, c2, (hipStream_t)stream);
+  return launch_dense_layer(c1, c2, (hipStream_t)stream);
 }
 
 // fp16-storage twins of the layers between the convolutions (inference only)
@@ -409,6 +419,20 @@ int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, con
   return MISEG_OK;
 }
 
+int miseg_plan_add_dense_layer(miseg_plan* p, const miseg_conv_desc* c1, const miseg_conv_desc* c2) {
+  MISEG_CHECK_ARG(p && c1 && c2, "plan: null argument");
+  MISEG_CHECK_ARG(c1->fmt == p->fmt && c2->fmt == p->fmt,
+                  "plan: the convolutions' storage format differs from the plan's (%d)", p->fmt);
+  int rc = validate_dense_layer(c1, c2);
+  if (rc != MISEG_OK) return rc;
+  Op o{};
+  o.kind = OP_DENSE;
+  o.conv = *c1;
+  o.conv2 = *c2;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
                               const float* shift, int32_t N, int32_t H, int32_t W) {
   MISEG_CHECK_ARG(p, "plan: null plan");
@@ -506,8 +530,10 @@ int miseg_plan_run(const miseg_plan* p, void* stream) {
 int64_t miseg_plan_op_macs(const miseg_plan* p, int index) {
   if (!p || index < 0 || index >= (int)p->ops.size()) return 0;
   const Op& o = p->ops[index];
-  if (o.kind != OP_CONV && o.kind != OP_CONV_HEAD) return 0;
+  if (o.kind != OP_CONV && o.kind != OP_CONV_HEAD && o.kind != OP_DENSE) return 0;
   const miseg_conv_desc& d = o.conv;
+  if (o.kind == OP_DENSE)   // the layer's own arithmetic (the kernel recomputes the 1x1 on the 3x3's halo)
+    return (int64_t)d.N * d.H * d.W * ((int64_t)d.Cin * 128 + 9 * 128 * 32);
   int64_t per = (int64_t)d.N * d.Ho * d.Wo * d.Cout * d.KH * d.KW * d.Cin;
   // the 7x7x3 stem runs as 7x1 taps over 8 pixels x 4 channels (K = 224): count the layer's own 147
   if (d.KH == 7 && d.KW == 1 && d.Cin == 32 && d.stride_y == 2) per = (int64_t)d.N * d.Ho * d.Wo * d.Cout * 147;
@@ -526,6 +552,8 @@ int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t bufl
     conv_kernel_name(&o.conv, buf, buflen);
   else if (o.kind == OP_CONV_HEAD)
     snprintf(buf, buflen, "conv3x3_c32_head_kernel");
+  else if (o.kind == OP_DENSE)
+    snprintf(buf, buflen, "dense_layer_kernel");
   else
     snprintf(buf, buflen, "%s", names[o.kind]);
   return MISEG_OK;

@@ -1086,4 +1086,63 @@ int launch_conv_c32_head(const miseg_conv_desc* b, const miseg_conv_desc* h, hip
   return MISEG_OK;
 }
 
+hipError_t launch_dense_layer_kernel(const ConvParams& c1, const ConvParams& c2, dim3 grid, hipStream_t s);
+int dense_layer_max_cin();
+
+// One DenseNet layer (BatchNorm + ReLU -> 1x1, C -> 128 -> BatchNorm + ReLU -> 3x3, 128 -> 32) in one
+// kernel; c1 describes the 1x1 convolution with its operand prologue, c2 the 3x3 convolution.
+int validate_dense_layer(const miseg_conv_desc* a, const miseg_conv_desc* b) {
+  MISEG_CHECK_ARG(a && b, "dense_layer: null descriptor");
+  MISEG_CHECK_ARG(a->in && a->weight && b->weight && b->out, "dense_layer: null pointer");
+  MISEG_CHECK_ARG(a->N > 0 && a->H > 0 && a->W > 0, "dense_layer: non-positive dimension");
+  const bool s1 = a->KH == 1 && a->KW == 1 && a->stride_y == 1 && a->stride_x == 1 && a->pad_y == 0 &&
+                  a->pad_x == 0 && a->Ho == a->H && a->Wo == a->W && !a->transposed && a->Cout == 128 &&
+                  a->Cin > 0 && (a->Cin & 31) == 0 && a->Cin <= dense_layer_max_cin();
+  const bool s2 = b->KH == 3 && b->KW == 3 && b->stride_y == 1 && b->stride_x == 1 && b->pad_y == 1 &&
+                  b->pad_x == 1 && b->Ho == b->H && b->Wo == b->W && !b->transposed && b->Cin == 128 &&
+                  b->Cout == 32;
+  if (!s1 || !s2) {
+    set_error("dense_layer: needs a 1x1 convolution C -> 128 (C %% 32 == 0, C <= %d) and a 3x3 stride-1 pad-1 "
+              "convolution 128 -> 32", dense_layer_max_cin());
+    return MISEG_E_UNSUPPORTED_SHAPE;
+  }
+  MISEG_CHECK_ARG(b->N == a->N && b->H == a->H && b->W == a->W, "dense_layer: the two convolutions' extents differ");
+  MISEG_CHECK_ARG(a->in_scale && a->in_shift && ((uintptr_t)a->in_scale & 15) == 0 && ((uintptr_t)a->in_shift & 15) == 0,
+                  "dense_layer: needs 16-byte aligned in_scale / in_shift");
+  MISEG_CHECK_ARG(a->act == MISEG_ACT_RELU && !a->residual && !a->out2 && !a->stats,
+                  "dense_layer: the 1x1 convolution takes scale/shift + ReLU only");
+  MISEG_CHECK_ARG(b->act == MISEG_ACT_NONE && !b->residual && !b->out2 && !b->in_scale && !b->stats &&
+                      b->out_dtype == MISEG_DT_BF16,
+                  "dense_layer: the 3x3 convolution takes a plain 16-bit output (optional scale/shift)");
+  MISEG_CHECK_ARG((a->in_pix_stride & 7) == 0 && (a->in_row_stride & 7) == 0 && (a->in_img_stride & 7) == 0 &&
+                      ((uintptr_t)a->in & 15) == 0 && ((uintptr_t)a->weight & 15) == 0 && ((uintptr_t)b->weight & 15) == 0,
+                  "dense_layer: input/weights need 16-byte alignment and strides in multiples of 8");
+  MISEG_CHECK_ARG((b->out_pix_stride & 7) == 0 && (b->out_row_stride & 7) == 0 && (b->out_img_stride & 7) == 0 &&
+                      ((uintptr_t)b->out & 15) == 0,
+                  "dense_layer: output needs 16-byte alignment and strides in multiples of 8");
+  MISEG_CHECK_ARG((long long)a->H * a->in_row_stride * 2 < (1ll << 31) && (long long)128 * a->Cin * 2 < (1ll << 31),
+                  "dense_layer: image too large for 32-bit offsets");
+  if (a->scale) MISEG_CHECK_ARG(a->shift != nullptr, "dense_layer: scale without shift");
+  return MISEG_OK;
+}
+
+int launch_dense_layer(const miseg_conv_desc* a, const miseg_conv_desc* b, hipStream_t stream) {
+  int rc = validate_dense_layer(a, b);
+  if (rc != MISEG_OK) return rc;
+  ConvParams pa, pb;
+  fill_params(a, pa);
+  fill_params(b, pb);
+  pa.tiles_y = (a->H + 7) / 8;
+  pa.tiles_x = (a->W + 15) / 16;
+  pa.mtiles = a->N * pa.tiles_y * pa.tiles_x;
+  pa.ntiles = 1;
+  pb.tiles_y = pa.tiles_y; pb.tiles_x = pa.tiles_x; pb.mtiles = pa.mtiles; pb.ntiles = 1;
+  hipError_t e = launch_dense_layer_kernel(pa, pb, dim3(pa.mtiles), stream);
+  if (e != hipSuccess) {
+    set_error("dense_layer launch failed: %s", hipGetErrorString(e));
+    return MISEG_E_HIP;
+  }
+  return MISEG_OK;
+}
+
 }  // namespace MISEG_KNS

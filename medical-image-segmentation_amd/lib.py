@@ -68,6 +68,7 @@ SIGNATURES = {
     "miseg_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), _VP]),
     "miseg_conv_kernel_name": (C.c_int, [C.POINTER(ConvDesc), C.c_char_p, _I32]),
     "miseg_conv_c32_head_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _VP]),
+    "miseg_dense_layer_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _VP]),
     "miseg_prep_input": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
     "miseg_prep_input_indicator": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
     "miseg_maxpool3x3s2_fwd": (C.c_int, [_VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
@@ -121,6 +122,7 @@ SIGNATURES = {
     "miseg_plan_set_format": (C.c_int, [_VP, _I32]),
     "miseg_plan_add_conv": (C.c_int, [_VP, C.POINTER(ConvDesc)]),
     "miseg_plan_add_conv_c32_head": (C.c_int, [_VP, C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
+    "miseg_plan_add_dense_layer": (C.c_int, [_VP, C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "miseg_plan_add_prep_input": (C.c_int, [_VP, _FP, _VP, _FP, _FP, _I32, _I32, _I32]),
     "miseg_plan_add_maxpool3x3s2": (C.c_int, [_VP, _VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32]),
     "miseg_plan_add_avgpool2x2": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
