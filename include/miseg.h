@@ -76,7 +76,8 @@ int miseg_device_check(void);
  *   A = in, or relu(in*in_scale[ci] + in_shift[ci]) when in_scale != NULL
  *       (taps outside the image contribute zero in both cases);
  *   v    = acc*scale[co] + shift[co] (+ residual[n,oy,ox,co]);
- *   out  = act(v)                           (dtype out_dtype; skipped if out == NULL)
+ *   out  = act(v)                           (dtype out_dtype; skipped if out == NULL;
+ *                                            with res_after_act the residual is added to act(v) instead)
  *   out2 = relu(v*scale2[co] + shift2[co])  (bf16; skipped if out2 == NULL)
  *
  * transposed == 1 selects Conv2DTranspose(kernel 4, stride 2, 'same'): the call
@@ -141,6 +142,10 @@ typedef struct miseg_conv_desc {
   int32_t stats_stride;
   int32_t fmt;   /* MISEG_FMT_*: format of in, weight, out2 and of out / residual where their dtype is
                     MISEG_DT_BF16 (read: "16-bit"). */
+  int32_t res_after_act; /* non-zero: out = act(v) + residual with v = acc*scale + shift, i.e. the
+                            Add([relu(bn(conv)), skip]) of the LinkNet decoder blocks
+                            (segmentation_models DecoderBlock, reached from utils/model.py:188-198),
+                            instead of out = act(v + residual); needs residual, no out2 */
 } miseg_conv_desc;
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);

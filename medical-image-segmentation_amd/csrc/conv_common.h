@@ -55,6 +55,7 @@ struct ConvParams {
   int tiles_y, tiles_x;  // halo kernel: output patches per image
   double* stats;         // optional per-channel sum / sum of squares of the stored bf16 output
   int stats_rep, stats_stride;
+  int res_after;         // the residual is added after the activation (out = act(v) + residual)
   int dgrad_t;           // data gradient of Conv2DTranspose(4, 2): `in` is dY, taps run over its four phase lattices
 };
 
@@ -270,26 +271,32 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
           v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w;
           v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
         }
+        float rr[8];
         if (has_res) {
           if (p.res_dtype == MISEG_DT_F32) {
             const float* rp = reinterpret_cast<const float*>(p.residual) + r_off;
             const float4 r0 = *reinterpret_cast<const float4*>(rp);
             const float4 r1 = *reinterpret_cast<const float4*>(rp + 4);
-            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-            v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+            rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w;
+            rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
           } else {
             const uint4 r = *reinterpret_cast<const uint4*>(
                 reinterpret_cast<const h16_t*>(p.residual) + r_off);
-            v[0] += h16lo_to_f32(r.x); v[1] += h16hi_to_f32(r.x);
-            v[2] += h16lo_to_f32(r.y); v[3] += h16hi_to_f32(r.y);
-            v[4] += h16lo_to_f32(r.z); v[5] += h16hi_to_f32(r.z);
-            v[6] += h16lo_to_f32(r.w); v[7] += h16hi_to_f32(r.w);
+            rr[0] = h16lo_to_f32(r.x); rr[1] = h16hi_to_f32(r.x);
+            rr[2] = h16lo_to_f32(r.y); rr[3] = h16hi_to_f32(r.y);
+            rr[4] = h16lo_to_f32(r.z); rr[5] = h16hi_to_f32(r.z);
+            rr[6] = h16lo_to_f32(r.w); rr[7] = h16hi_to_f32(r.w);
+          }
+          if (!p.res_after) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rr[j];
           }
         }
+        const bool radd = has_res && p.res_after;
         if (p.out) {
           float w[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) w[j] = p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
+          for (int j = 0; j < 8; ++j) w[j] = (p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j]) + (radd ? rr[j] : 0.f);
           if (p.out_dtype == MISEG_DT_F32) {
             float* o = reinterpret_cast<float*>(p.out) + o_off;
             *reinterpret_cast<float4*>(o) = make_float4(w[0], w[1], w[2], w[3]);
@@ -298,6 +305,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
             float u[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) u[j] = h16_act(v[j], p.act == MISEG_ACT_RELU);
+            if (radd) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) u[j] = h16_act(u[j] + rr[j], false);
+            }
             const uint4 pk = make_uint4(pack_h16x2_raw(u[0], u[1]), pack_h16x2_raw(u[2], u[3]),
                                         pack_h16x2_raw(u[4], u[5]), pack_h16x2_raw(u[6], u[7]));
             *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + o_off) = pk;
@@ -327,15 +338,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
         continue;
       }
       // ---- partial channel group (Cout tail, unaligned strides, or the softmax head) ----
+      float rp[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (cox + j < p.Cout) {
           if (p.scale) v[j] *= p.scale[cox + j];
           if (p.shift) v[j] += p.shift[cox + j];
-          if (has_res)
-            v[j] += p.res_dtype == MISEG_DT_F32
+          if (has_res) {
+            rp[j] = p.res_dtype == MISEG_DT_F32
                         ? reinterpret_cast<const float*>(p.residual)[r_off + j]
                         : h16_to_f32(reinterpret_cast<const h16_t*>(p.residual)[r_off + j]);
+            if (!p.res_after) v[j] += rp[j];
+          }
         }
       }
       if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID) {
@@ -348,7 +362,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
       for (int j = 0; j < 8; ++j) {
         if (cox + j >= p.Cout) continue;
         if (p.out) {
-          const float w = p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j];
+          const float w = (p.act == MISEG_ACT_RELU ? fmaxf(v[j], 0.f) : v[j]) + ((has_res && p.res_after) ? rp[j] : 0.f);
           if (p.out_dtype == MISEG_DT_F32)
             reinterpret_cast<float*>(p.out)[o_off + j] = w;
           else
@@ -475,14 +489,20 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
     }
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = v[j] * d.sc[j] + d.sh[j];
+  float rr[16];
+  const bool radd = has_res && p.res_after;
   if (has_res) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const uint4 r = res[q];
-      v[8 * q + 0] += h16lo_to_f32(r.x); v[8 * q + 1] += h16hi_to_f32(r.x);
-      v[8 * q + 2] += h16lo_to_f32(r.y); v[8 * q + 3] += h16hi_to_f32(r.y);
-      v[8 * q + 4] += h16lo_to_f32(r.z); v[8 * q + 5] += h16hi_to_f32(r.z);
-      v[8 * q + 6] += h16lo_to_f32(r.w); v[8 * q + 7] += h16hi_to_f32(r.w);
+      rr[8 * q + 0] = h16lo_to_f32(r.x); rr[8 * q + 1] = h16hi_to_f32(r.x);
+      rr[8 * q + 2] = h16lo_to_f32(r.y); rr[8 * q + 3] = h16hi_to_f32(r.y);
+      rr[8 * q + 4] = h16lo_to_f32(r.z); rr[8 * q + 5] = h16hi_to_f32(r.z);
+      rr[8 * q + 6] = h16lo_to_f32(r.w); rr[8 * q + 7] = h16hi_to_f32(r.w);
+    }
+    if (!radd) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] += rr[j];
     }
   }
 #pragma unroll
@@ -492,6 +512,10 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
     float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = h16_act(w[j], d.relu);
+    if (radd) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = h16_act(o[j] + rr[8 * q + j], false);
+    }
     const uint4 pk = make_uint4(pack_h16x2_raw(o[0], o[1]), pack_h16x2_raw(o[2], o[3]), pack_h16x2_raw(o[4], o[5]),
                                 pack_h16x2_raw(o[6], o[7]));
     *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + o_off + d.c2[q]) = pk;

@@ -726,6 +726,9 @@ int validate_conv(const miseg_conv_desc* d) {
   } else if (d->out2) {
     MISEG_CHECK_ARG(d->scale2 && d->shift2, "conv: out2 needs scale2/shift2");
   }
+  if (d->res_after_act)
+    MISEG_CHECK_ARG(d->residual && !d->out2 && d->act != MISEG_ACT_SOFTMAX && d->act != MISEG_ACT_SIGMOID,
+                    "conv: res_after_act needs a residual, no second output and no head activation");
   if (d->in_scale || d->in_shift) {
     MISEG_CHECK_ARG(d->in_scale && d->in_shift, "conv: prologue needs both in_scale and in_shift");
     MISEG_CHECK_ARG(((uintptr_t)d->in_scale & 15) == 0 && ((uintptr_t)d->in_shift & 15) == 0,
@@ -883,6 +886,7 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.stats_stride = d->stats_stride;
   p.M = d->N * d->Ho * d->Wo;
   p.dgrad_t = 0;
+  p.res_after = d->res_after_act ? 1 : 0;
   auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
     return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
   };

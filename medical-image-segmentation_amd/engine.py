@@ -193,7 +193,7 @@ class Engine:
     def conv(self, name, x, wptr, cout, k, stride=1, pad=0, out=None, out_dtype=L.DT_BF16,
              scale=None, shift=None, act=L.ACT_NONE, residual=None, out2=None, scale2=None,
              shift2=None, in_scale=None, in_shift=None, transposed=False, collapse=None,
-             temperature=1.0, tile_hint=0, build_only=False):
+             temperature=1.0, tile_hint=0, build_only=False, res_after=False):
         d = L.ConvDesc()
         cin = _ceil32(x.c)
         if x.c0 + cin > x.ctot:
@@ -241,6 +241,7 @@ class Engine:
         d.collapse_value = self.collapse_value
         d.tile_hint = tile_hint
         d.fmt = self.fmt
+        d.res_after_act = 1 if res_after else 0
         pix_out = x.n * oh * ow
         nbytes = x.n * x.h * x.w * x.c * 2 + cout * d.KH * d.KW * cin * 2 * (4 if transposed else 1)
         if out is not None:
@@ -479,14 +480,10 @@ class Engine:
                 cout = self.w[base + "_conv"]["kernel"].shape[3]
                 out = self.buf(x.h, x.w, _ceil32(cout)).slice(0, cout)
                 s, t = self.bn_fold(base + "_bn")
-                # Add([relu(bn(conv)), skip]): the skip is added after the activation, so the
-                # convolution writes relu(bn(.)) and a second pass adds the skip in place.
+                # Add([relu(bn(conv)), skip]): the skip is added after the activation, in the
+                # convolution's epilogue
                 self.conv(base, x, self.conv_weight(base + "_conv"), cout, 1, out=out, scale=s,
-                          shift=t, act=L.ACT_RELU)
-                if i < 4:
-                    self._add(self.lib.miseg_plan_add_upsample_nearest(
-                        self.plan, out.ptr, skips[i].ptr, out.ptr, self.n, out.h, out.w, cout, 0,
-                        out.pix, skips[i].pix, out.pix), "decoder_stage%d_add" % i)
+                          shift=t, act=L.ACT_RELU, residual=skips[i] if i < 4 else None, res_after=i < 4)
                 self.taps["decoder_stage%d_out" % i] = out
                 x = out
             self._head("final_conv", x)

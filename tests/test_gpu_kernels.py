@@ -78,7 +78,7 @@ def dev_f32(a, dev):
 
 def run_conv(env, x, w_hwio, stride=1, pad=0, scale=None, shift=None, act=0, residual=None,
              res_f32=True, scale2=None, shift2=None, in_scale=None, in_shift=None, out_f32=False,
-             want_out=True, tile_hint=0, in_extra_c=0, out_extra_c=0):
+             want_out=True, tile_hint=0, in_extra_c=0, out_extra_c=0, res_after=False):
     """x: (N,H,W,Cin) fp32 (bf16-representable); returns (out, out2) as fp32 numpy."""
     L, lib, dev = env
     n, h, wd, cin = x.shape
@@ -128,6 +128,7 @@ def run_conv(env, x, w_hwio, stride=1, pad=0, scale=None, shift=None, act=0, res
     d.act = act
     d.temperature = 1.0
     d.tile_hint = tile_hint
+    d.res_after_act = 1 if res_after else 0
     L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
     torch.cuda.synchronize()
     o = out[..., out_extra_c:].float().cpu().numpy() if want_out else None
@@ -179,6 +180,34 @@ def test_conv_plain(env, case, hint):
     want = ref_conv(x, wt, stride, pad)
     # fp32 accumulation of identical bf16 operands: only summation order differs
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 64, 40), (1, 1, 96, 128), (3, 3, 64, 64), (3, 3, 128, 128), (3, 3, 32, 16)])
+@pytest.mark.parametrize("res_f32", [False, True])
+def test_conv_residual_after_activation(env, shape, res_f32):
+    """out = relu(conv*scale + shift) + residual: the Add([relu(bn(conv)), skip]) of the LinkNet decoder
+    blocks (segmentation_models DecoderBlock, /root/reference utils/model.py:188-198), on the generic
+    and on the direct epilogue."""
+    k, _, cin, cout = shape
+    rng = np.random.default_rng(cin * 1000 + cout + k)
+    n, h, w = 2, 11, 37
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    wt = bf16_round(rng.normal(0, 0.1, (k, k, cin, cout)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.5, cout).astype(np.float32)
+    res = rng.normal(0, 1, (n, h, w, cout)).astype(np.float32)
+    if not res_f32:
+        res = bf16_round(res)
+    base = ref_conv(x, wt, 1, k // 2)
+    want = np.maximum(base * sc + sh, 0) + res
+    for out_f32 in (False, True):
+        got, _ = run_conv(env, x, wt, 1, k // 2, scale=sc, shift=sh, act=1, residual=res, res_f32=res_f32,
+                          out_f32=out_f32, res_after=True)
+        tol = 1e-4 if out_f32 else 1e-2
+        np.testing.assert_allclose(got, want, rtol=tol, atol=tol * np.abs(want).max())
+    # the pre-activation form differs wherever the convolution's value is negative
+    pre, _ = run_conv(env, x, wt, 1, k // 2, scale=sc, shift=sh, act=1, residual=res, res_f32=res_f32, out_f32=True)
+    np.testing.assert_allclose(pre, np.maximum(base * sc + sh + res, 0), rtol=1e-4, atol=1e-4 * np.abs(want).max())
 
 
 def test_conv_epilogues(env):
