@@ -182,6 +182,44 @@ int miseg_conv_c32_head_fwd(const miseg_conv_desc* body, const miseg_conv_desc* 
 int miseg_dense_layer_fwd(const miseg_conv_desc* c1, const miseg_conv_desc* c2, void* stream);
 
 /*
+ * The tail of the LinkNet the reference builds at utils/model.py:188-198 as one kernel:
+ * segmentation_models DecoderBlock `decoder_stage4` -- `a`: Conv2D 1x1 64 -> 16, `b`:
+ * Conv2DTranspose(4, 2, 'same') 16 -> 16, `c`: Conv2D 1x1 16 -> 16, each with BatchNorm + ReLU
+ * (folded into scale/shift vectors of 16 floats) -- followed by `final_conv` (Conv2D 3x3
+ * 16 -> classes <= 4 with bias), softmax / sigmoid and the collapse_probabilities mask
+ * (utils/utils.py:50-68).  The three 16-channel full-resolution tensors stay on chip.
+ *   in : 16-bit [N][H][W][>= 64 channels] (strides in elements), the decoder's 64-channel
+ *        tensor at half resolution;
+ *   wa : [16][64]                      (cout, cin)
+ *   wb : [4][16][2][2][16]             (phase a*2+b, cout, dy, dx, cin) with
+ *        wb[(a,b)][co][dy][dx][ci] = kernel[3-a-2dy][3-b-2dx][co][ci] of the Keras layer
+ *   wc : [16][32]                      (cout, cin; cin >= 16 zero)
+ *   wd : [16][160]                     (class, tap*16 + cin; rows >= classes and k >= 144 zero)
+ *   out: fp32 [N][2H][2W][classes] probabilities (strides in elements);
+ *   collapse_out: u8 [N][2H][2W][classes] or NULL.
+ */
+typedef struct miseg_linknet_tail_desc {
+  const void* in;
+  const void *wa, *wb, *wc, *wd;
+  const float *sa, *ta, *sb, *tb, *sc, *tc;
+  const float* bias; /* [classes] or NULL */
+  float* out;
+  void* collapse_out;
+  int32_t N, H, W;
+  int32_t in_pix_stride, in_row_stride;
+  int64_t in_img_stride;
+  int32_t out_pix_stride, out_row_stride;
+  int64_t out_img_stride;
+  int32_t classes;
+  int32_t act; /* MISEG_ACT_SOFTMAX or MISEG_ACT_SIGMOID */
+  float temperature;
+  int32_t collapse_value;
+  int32_t fmt; /* MISEG_FMT_* of in and the weights */
+} miseg_linknet_tail_desc;
+
+int miseg_linknet_tail_fwd(const miseg_linknet_tail_desc* d, void* stream);
+
+/*
  * Input contract of the encoders: fp32 NHWC image with 3 channels ->
  * bf16 [N][H+6][W+8][4] with the image at rows 3.., columns 3.., channel 3 and
  * the border zero; value = x*scale[c] + shift[c] (ResNet `bn_data`, a
@@ -477,6 +515,7 @@ int miseg_plan_set_format(miseg_plan* p, int32_t fmt);
 int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d);
 int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, const miseg_conv_desc* head);
 int miseg_plan_add_dense_layer(miseg_plan* p, const miseg_conv_desc* c1, const miseg_conv_desc* c2);
+int miseg_plan_add_linknet_tail(miseg_plan* p, const miseg_linknet_tail_desc* d);
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
                               const float* shift, int32_t N, int32_t H, int32_t W);
 int miseg_plan_add_maxpool3x3s2(miseg_plan* p, const void* in, void* out, const float* scale,

@@ -65,11 +65,12 @@ namespace miseg_f16 {
 }
 namespace miseg {
 
-enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD, OP_DENSE };
+enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD, OP_DENSE, OP_LTAIL };
 
 struct Op {
   OpKind kind;
   miseg_conv_desc conv;
+  miseg_linknet_tail_desc tail;   // OP_LTAIL
   miseg_conv_desc conv2;   // OP_CONV_HEAD: the head convolution; OP_DENSE: the 3x3 convolution
   const void* in;
   const void* in2;
@@ -86,6 +87,7 @@ static int run_op_f16(const Op& o, hipStream_t s) {
     case OP_CONV: return F::launch_conv(&o.conv, s);
     case OP_CONV_HEAD: return F::launch_conv_c32_head(&o.conv, &o.conv2, s);
     case OP_DENSE: return F::launch_dense_layer(&o.conv, &o.conv2, s);
+    case OP_LTAIL: return F::launch_linknet_tail(&o.tail, s);
     case OP_PREP: return F::launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
     case OP_MAXPOOL:
       return F::launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
@@ -107,6 +109,7 @@ static int run_op(const Op& o, hipStream_t s, int fmt) {
     case OP_CONV: return launch_conv(&o.conv, s);
     case OP_CONV_HEAD: return launch_conv_c32_head(&o.conv, &o.conv2, s);
     case OP_DENSE: return launch_dense_layer(&o.conv, &o.conv2, s);
+    case OP_LTAIL: return launch_linknet_tail(&o.tail, s);
     case OP_PREP: return launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
@@ -186,6 +189,13 @@ int miseg_dense_layer_fwd(const miseg_conv_desc* c1, const miseg_conv_desc* c2, 
   MISEG_CHECK_ARG(c1->fmt == c2->fmt, "dense_layer: the two convolutions must use one storage format");
   if (c1->fmt == MISEG_FMT_F16) return miseg_f16::launch_dense_layer(c1, c2, (hipStream_t)stream);
   return launch_dense_layer(c1, c2, (hipStream_t)stream);
+}
+
+int miseg_linknet_tail_fwd(const miseg_linknet_tail_desc* d, void* stream) {
+  MISEG_CHECK_ARG(d, "linknet_tail: null descriptor");
+  MISEG_CHECK_FMT(d->fmt);
+  if (d->fmt == MISEG_FMT_F16) return miseg_f16::launch_linknet_tail(d, (hipStream_t)stream);
+  return launch_linknet_tail(d, (hipStream_t)stream);
 }
 
 // fp16-storage twins of the layers between the convolutions (inference only)
@@ -433,6 +443,17 @@ int miseg_plan_add_dense_layer(miseg_plan* p, const miseg_conv_desc* c1, const m
   return MISEG_OK;
 }
 
+int miseg_plan_add_linknet_tail(miseg_plan* p, const miseg_linknet_tail_desc* d) {
+  MISEG_CHECK_ARG(p && d, "plan: null argument");
+  MISEG_CHECK_ARG(d->fmt == p->fmt, "plan: the tail's storage format differs from the plan's (%d)", p->fmt);
+  MISEG_CHECK_ARG(d->in && d->wa && d->wb && d->wc && d->wd && d->out, "linknet_tail: null pointer");
+  Op o{};
+  o.kind = OP_LTAIL;
+  o.tail = *d;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
                               const float* shift, int32_t N, int32_t H, int32_t W) {
   MISEG_CHECK_ARG(p, "plan: null plan");
@@ -530,6 +551,10 @@ int miseg_plan_run(const miseg_plan* p, void* stream) {
 int64_t miseg_plan_op_macs(const miseg_plan* p, int index) {
   if (!p || index < 0 || index >= (int)p->ops.size()) return 0;
   const Op& o = p->ops[index];
+  if (o.kind == OP_LTAIL) {   // per input pixel: 64*16 (a) + 4 phases * 4 taps * 16*16 (b); per output pixel: 16*16 + 9*16*classes
+    const miseg_linknet_tail_desc& t = o.tail;
+    return (int64_t)t.N * t.H * t.W * (64 * 16 + 4 * 4 * 256 + 4 * (256 + 144 * t.classes));
+  }
   if (o.kind != OP_CONV && o.kind != OP_CONV_HEAD && o.kind != OP_DENSE) return 0;
   const miseg_conv_desc& d = o.conv;
   if (o.kind == OP_DENSE)   // the layer's own arithmetic (the kernel recomputes the 1x1 on the 3x3's halo)
@@ -554,6 +579,8 @@ int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t bufl
     snprintf(buf, buflen, "conv3x3_c32_head_kernel");
   else if (o.kind == OP_DENSE)
     snprintf(buf, buflen, "dense_layer_kernel");
+  else if (o.kind == OP_LTAIL)
+    snprintf(buf, buflen, "linknet_tail_kernel");
   else
     snprintf(buf, buflen, "%s", names[o.kind]);
   return MISEG_OK;

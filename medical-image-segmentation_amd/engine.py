@@ -435,6 +435,44 @@ class Engine:
         self._add(self.lib.miseg_plan_add_conv_c32_head(self.plan, C.byref(body), C.byref(hd)),
                   base + "+" + head, nb + nh)
 
+    def _linknet_tail_ok(self, x):
+        w = self.w
+        return (x.c == 64 and self.classes <= 4 and
+                w["decoder_stage4a_conv"]["kernel"].shape[3] == 16 and
+                w["decoder_stage4b_transpose"]["kernel"].shape[2:] == (16, 16) and
+                w["decoder_stage4c_conv"]["kernel"].shape[2:] == (16, 16) and
+                w["final_conv"]["kernel"].shape[:3] == (3, 3, 16))
+
+    def _linknet_tail(self, x):
+        """decoder_stage4 (1x1 64 -> 16, transpose 16 -> 16, 1x1 16 -> 16, each BN + ReLU) + final_conv +
+        activation + collapse as one kernel: none of the 16-channel full-resolution tensors reaches HBM."""
+        d = L.LinknetTailDesc()
+        d.inp = x.ptr
+        d.wa = self.conv_weight("decoder_stage4a_conv", cin_pad=64)
+        d.wb = self.convT_weight("decoder_stage4b_transpose", cin_pad=16)
+        d.wc = self.conv_weight("decoder_stage4c_conv", cin_pad=32)
+        k = self.w["final_conv"]["kernel"]                      # (3, 3, 16, classes)
+        wd = np.zeros((16, 160), np.float32)
+        wd[:self.classes, :144] = k.transpose(3, 0, 1, 2).reshape(self.classes, 144)
+        d.wd = self.dev_h16(wd)
+        for key, bn in (("a", "decoder_stage4a_bn"), ("b", "decoder_stage4b_bn"), ("c", "decoder_stage4c_bn")):
+            sc, sh = self.bn_fold(bn)
+            setattr(d, "s" + key, self.dev_f32(sc))
+            setattr(d, "t" + key, self.dev_f32(sh))
+        d.bias = self.dev_f32(self.w["final_conv"]["bias"])
+        d.out, d.collapse_out = self.probs.data_ptr(), self.mask.data_ptr()
+        d.N, d.H, d.W = x.n, x.h, x.w
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = x.pix, x.row, x.img
+        c = self.classes
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = c, c * self.wd, c * self.wd * self.h
+        d.classes = c
+        d.act = L.ACT_SIGMOID if self.g.activation == "sigmoid" else L.ACT_SOFTMAX
+        d.temperature = self.g.temperature if self.g.temperature is not None else 1.0
+        d.collapse_value = self.collapse_value
+        d.fmt = self.fmt
+        nbytes = x.n * x.h * x.w * 64 * 2 + self.n * self.h * self.wd * c * 5
+        self._add(self.lib.miseg_plan_add_linknet_tail(self.plan, C.byref(d)), "decoder_stage4+final_conv", nbytes)
+
     def _lower(self):
         g = self.g
         enc, dec = g.encoder, g.decoder
@@ -474,6 +512,10 @@ class Engine:
                 self._head("final_conv", x)
         elif dec == "Linknet":
             for i in range(5):
+                if i == 4 and self.fuse_tail and self._linknet_tail_ok(x):
+                    self._linknet_tail(x)
+                    x = None
+                    break
                 x = self.conv_bn_relu("decoder_stage%da" % i, x, 1)
                 x = self.convT_bn_relu("decoder_stage%db_transpose" % i, "decoder_stage%db_bn" % i, x)
                 base = "decoder_stage%dc" % i
@@ -486,7 +528,8 @@ class Engine:
                           shift=t, act=L.ACT_RELU, residual=skips[i] if i < 4 else None, res_after=i < 4)
                 self.taps["decoder_stage%d_out" % i] = out
                 x = out
-            self._head("final_conv", x)
+            if x is not None:
+                self._head("final_conv", x)
         else:  # FPN
             pyr = []
             for j, st in enumerate((5, 4, 3, 2)):

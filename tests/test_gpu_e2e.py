@@ -31,6 +31,8 @@ CONFIGS = [
     ("resnet18", "FPN", (64, 64), 4, 3),       # four images: on one, the score bars are decided by a few near-tie pixels
     ("resnet18", "Linknet", (64, 64), 1, 3),
     ("densenet121", "U-Net", (64, 64), 1, 3),
+    ("resnet18", "Linknet", (96, 160), 2, 1),  # fused tail: ragged 8x64 output patches, sigmoid head
+    ("resnet34", "Linknet", (64, 128), 1, 4),  # fused tail: whole patches (vector stores), four classes
 ]
 
 
@@ -110,6 +112,14 @@ def test_engine_residual_stream_options():
     check_engine("resnet34", "U-Net", (96, 64), 1, 3, residual_bf16=False)
     check_engine("resnet34", "U-Net", (96, 64), 1, 3, residual_bf16=True, storage="bf16")
     check_engine("resnet18", "Linknet", (64, 64), 1, 3, residual_bf16=True, storage="bf16")
+
+
+def test_layerwise_forms_of_fused_kernels():
+    """The fused kernels (U-Net / LinkNet tails, DenseNet layers) can be switched off: the layer-by-layer
+    plans must clear the same bars."""
+    check_engine("resnet18", "Linknet", (96, 160), 2, 3, fuse_tail=False)
+    check_engine("densenet121", "Linknet", (64, 96), 1, 3, fuse_tail=False, fuse_dense=False)
+    check_engine("resnet18", "U-Net", (64, 96), 2, 3, fuse_tail=False)
 
 
 def check_engine(enc, dec, hw, n, classes, **engine_options):
