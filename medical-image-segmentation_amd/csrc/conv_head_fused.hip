@@ -59,10 +59,23 @@ __device__ __forceinline__ void lds_barrier() {
 }
 }  // namespace
 
+#ifdef MISEG_HF_PROFILE
+// phase timers of wave w of block b (100 MHz ticks): [0] top barrier, [1] halo requests, [2] body
+// arithmetic, [3] barrier + intermediate tile, [4] barrier + head arithmetic, [5] vmcnt wait,
+// [6] activation + stores, [7] patches
+__device__ unsigned long long g_hf_prof[4096][8];
+#define HF_TICK(i) do { const unsigned long long t__ = wall_clock64(); hf_t[i] += t__ - hf_last; hf_last = t__; } while (0)
+#else
+#define HF_TICK(i) do { } while (0)
+#endif
+
 // body: the 32 -> 32 convolution (in, weight, scale, shift; its out pointers are unused);
 // head: the 32 -> classes convolution (weight, scale, shift, act, out, collapse_out, ...).
 __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvParams p, const ConvParams hd) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[HF_LDS];
+#ifdef MISEG_HF_PROFILE
+  unsigned long long hf_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hf_last = wall_clock64();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,11 +94,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
     y0 = tyi * HF_TH;
     x0 = (trem - tyi * p.tiles_x) * HF_TW;
   };
+  // halo sources relative to the halo's first pixel (element offsets; -1 = a row past the halo):
+  // patches whose halo lies inside the image need no per-lane bounds checks
+  constexpr int NHJ = (HF_NII + 3) / 4;
+  int h_rel[NHJ];
+#pragma unroll
+  for (int j = 0; j < NHJ; ++j) {
+    const int hr = (j * 4 + wave) * 16 + r16;
+    const int hy = hr / HF_IW;
+    const int hx = hr - hy * HF_IW;
+    h_rel[j] = hr < HF_IROWS ? hy * p.in_row_stride + hx * p.in_pix_stride + (slot ^ ((hr >> 2) & 3)) * 8 : -1;
+  }
   // LDS-DMA of the input halo of `tile` into buffer `buf`
   auto issue_halo = [&](int tile, int buf) {
     int n, y0, x0;
     patch_origin(tile, n, y0, x0);
     const h16_t* img = p.in + n * p.in_img_stride;
+    if (y0 >= 2 && y0 + HF_TH + 2 <= p.H && x0 >= 2 && x0 + HF_TW + 2 <= p.W) {   // block-uniform
+      const h16_t* org = img + (long long)(y0 - 2) * p.in_row_stride + (long long)(x0 - 2) * p.in_pix_stride;
+#pragma unroll
+      for (int j = 0; j < NHJ; ++j) {
+        const int i = j * 4 + wave;
+        if (i < HF_NII) {
+          const h16_t* src = h_rel[j] >= 0 ? org + h_rel[j] : zero_src;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)src,
+              (__attribute__((address_space(3))) void*)(lds + buf * HF_IN_BYTES + i * 1024), 16, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < (HF_NII + 3) / 4; ++j) {
       const int i = j * 4 + wave;
@@ -170,9 +208,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
     // stores of the previous patch) and has left the previous patch, whose buffer the next
     // request overwrites
     lds_barrier();
+    HF_TICK(0);
     if (tile + (int)gridDim.x < p.mtiles) issue_halo(tile + gridDim.x, cur ^ 1);
     int n, y0, x0;
     patch_origin(tile, n, y0, x0);
+    HF_TICK(1);
 
     // ---- body: 18 K-steps (tap x 16-deep half); the fragments of step s + 2 are requested
     // right after the MFMAs of step s, so two steps of reads are always in flight ----
@@ -208,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
         if constexpr (st + 2 < 18) issue(std::integral_constant<int, st + 2>{});
       });
     }
+    HF_TICK(2);
     lds_barrier();   // every wave is done reading the halo: the intermediate tile overlays it
     // scale/shift + ReLU -> bf16; lane: pixel lrow of the tile, channels 8g + 4*lhalf + i
     // (read by hand: a compiler-visible LDS read here would first drain vmcnt, i.e. wait for the
@@ -251,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
         }
       }
     }
+    HF_TICK(3);
     lds_barrier();
 
     // ---- head: wave -> output rows 2*wave, 2*wave + 1, two 16-pixel tiles per row ----
@@ -292,7 +334,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
     // The next patch's halo, requested two stages ago, must have landed before the loop comes
     // round; waiting here, BEFORE this patch's stores are issued, keeps the slow store
     // acknowledgements out of that wait (vmcnt retires in order).
+    HF_TICK(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HF_TICK(5);
     {
       float* sw = reinterpret_cast<float*>(lds + HF_SCR_OFF + wave * HF_SCR_WAVE);
       uint8_t* sm = reinterpret_cast<uint8_t*>(sw) + 1024;
@@ -357,7 +401,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_head_kernel(const ConvPara
           }
       }
     }
+    HF_TICK(6);
+#ifdef MISEG_HF_PROFILE
+    hf_t[7] += 1;
+#endif
   }
+#ifdef MISEG_HF_PROFILE
+  if (lane == 0 && blockIdx.x < 1024)
+    for (int i = 0; i < 8; ++i) g_hf_prof[blockIdx.x * 4 + wave][i] = hf_t[i];
+#endif
 }
 
 hipError_t launch_c32_head(const ConvParams& body, const ConvParams& head, dim3 grid, hipStream_t s) {
