@@ -220,6 +220,37 @@ typedef struct miseg_linknet_tail_desc {
 int miseg_linknet_tail_fwd(const miseg_linknet_tail_desc* d, void* stream);
 
 /*
+ * The end of the FPN the reference builds at utils/model.py:200-211 as one kernel:
+ * `final_upsampling` (UpSampling2D(2, interpolation='bilinear'): half-pixel centres, clamped
+ * edges) + `head_conv` (Conv2D 3x3 128 -> classes <= 4 with bias, zero padding) + softmax /
+ * sigmoid + the collapse_probabilities mask (utils/utils.py:50-68).  The up-sampled 128-channel
+ * tensor stays on chip; its values are rounded to the storage format exactly as
+ * miseg_upsample_bilinear2x_fwd would store them.
+ *   in : 16-bit [N][H][W][>= 128 channels] (strides in elements);
+ *   wd : [16][9][128]  (class, tap = dy*3 + dx, cin; rows >= classes zero)
+ *   out: fp32 [N][2H][2W][classes]; collapse_out: u8 [N][2H][2W][classes] or NULL.
+ */
+typedef struct miseg_fpn_head_desc {
+  const void* in;
+  const void* wd;
+  const float* bias; /* [classes] or NULL */
+  float* out;
+  void* collapse_out;
+  int32_t N, H, W;
+  int32_t in_pix_stride, in_row_stride;
+  int64_t in_img_stride;
+  int32_t out_pix_stride, out_row_stride;
+  int64_t out_img_stride;
+  int32_t classes;
+  int32_t act; /* MISEG_ACT_SOFTMAX or MISEG_ACT_SIGMOID */
+  float temperature;
+  int32_t collapse_value;
+  int32_t fmt;
+} miseg_fpn_head_desc;
+
+int miseg_fpn_head_fwd(const miseg_fpn_head_desc* d, void* stream);
+
+/*
  * Input contract of the encoders: fp32 NHWC image with 3 channels ->
  * bf16 [N][H+6][W+8][4] with the image at rows 3.., columns 3.., channel 3 and
  * the border zero; value = x*scale[c] + shift[c] (ResNet `bn_data`, a
@@ -516,6 +547,7 @@ int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d);
 int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, const miseg_conv_desc* head);
 int miseg_plan_add_dense_layer(miseg_plan* p, const miseg_conv_desc* c1, const miseg_conv_desc* c2);
 int miseg_plan_add_linknet_tail(miseg_plan* p, const miseg_linknet_tail_desc* d);
+int miseg_plan_add_fpn_head(miseg_plan* p, const miseg_fpn_head_desc* d);
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
                               const float* shift, int32_t N, int32_t H, int32_t W);
 int miseg_plan_add_maxpool3x3s2(miseg_plan* p, const void* in, void* out, const float* scale,

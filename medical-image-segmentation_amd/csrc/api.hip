@@ -65,12 +65,13 @@ namespace miseg_f16 {
 }
 namespace miseg {
 
-enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD, OP_DENSE, OP_LTAIL };
+enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD, OP_DENSE, OP_LTAIL, OP_FPNHEAD };
 
 struct Op {
   OpKind kind;
   miseg_conv_desc conv;
   miseg_linknet_tail_desc tail;   // OP_LTAIL
+  miseg_fpn_head_desc fhead;      // OP_FPNHEAD
   miseg_conv_desc conv2;   // OP_CONV_HEAD: the head convolution; OP_DENSE: the 3x3 convolution
   const void* in;
   const void* in2;
@@ -88,6 +89,7 @@ static int run_op_f16(const Op& o, hipStream_t s) {
     case OP_CONV_HEAD: return F::launch_conv_c32_head(&o.conv, &o.conv2, s);
     case OP_DENSE: return F::launch_dense_layer(&o.conv, &o.conv2, s);
     case OP_LTAIL: return F::launch_linknet_tail(&o.tail, s);
+    case OP_FPNHEAD: return F::launch_fpn_head(&o.fhead, s);
     case OP_PREP: return F::launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
     case OP_MAXPOOL:
       return F::launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
@@ -110,6 +112,7 @@ static int run_op(const Op& o, hipStream_t s, int fmt) {
     case OP_CONV_HEAD: return launch_conv_c32_head(&o.conv, &o.conv2, s);
     case OP_DENSE: return launch_dense_layer(&o.conv, &o.conv2, s);
     case OP_LTAIL: return launch_linknet_tail(&o.tail, s);
+    case OP_FPNHEAD: return launch_fpn_head(&o.fhead, s);
     case OP_PREP: return launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
@@ -196,6 +199,13 @@ int miseg_linknet_tail_fwd(const miseg_linknet_tail_desc* d, void* stream) {
   MISEG_CHECK_FMT(d->fmt);
   if (d->fmt == MISEG_FMT_F16) return miseg_f16::launch_linknet_tail(d, (hipStream_t)stream);
   return launch_linknet_tail(d, (hipStream_t)stream);
+}
+
+int miseg_fpn_head_fwd(const miseg_fpn_head_desc* d, void* stream) {
+  MISEG_CHECK_ARG(d, "fpn_head: null descriptor");
+  MISEG_CHECK_FMT(d->fmt);
+  if (d->fmt == MISEG_FMT_F16) return miseg_f16::launch_fpn_head(d, (hipStream_t)stream);
+  return launch_fpn_head(d, (hipStream_t)stream);
 }
 
 // fp16-storage twins of the layers between the convolutions (inference only)
@@ -454,6 +464,17 @@ int miseg_plan_add_linknet_tail(miseg_plan* p, const miseg_linknet_tail_desc* d)
   return MISEG_OK;
 }
 
+int miseg_plan_add_fpn_head(miseg_plan* p, const miseg_fpn_head_desc* d) {
+  MISEG_CHECK_ARG(p && d, "plan: null argument");
+  MISEG_CHECK_ARG(d->fmt == p->fmt, "plan: the head's storage format differs from the plan's (%d)", p->fmt);
+  MISEG_CHECK_ARG(d->in && d->wd && d->out, "fpn_head: null pointer");
+  Op o{};
+  o.kind = OP_FPNHEAD;
+  o.fhead = *d;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
                               const float* shift, int32_t N, int32_t H, int32_t W) {
   MISEG_CHECK_ARG(p, "plan: null plan");
@@ -555,6 +576,7 @@ int64_t miseg_plan_op_macs(const miseg_plan* p, int index) {
     const miseg_linknet_tail_desc& t = o.tail;
     return (int64_t)t.N * t.H * t.W * (64 * 16 + 4 * 4 * 256 + 4 * (256 + 144 * t.classes));
   }
+  if (o.kind == OP_FPNHEAD) return (int64_t)o.fhead.N * o.fhead.H * o.fhead.W * 4 * 9 * 128 * o.fhead.classes;
   if (o.kind != OP_CONV && o.kind != OP_CONV_HEAD && o.kind != OP_DENSE) return 0;
   const miseg_conv_desc& d = o.conv;
   if (o.kind == OP_DENSE)   // the layer's own arithmetic (the kernel recomputes the 1x1 on the 3x3's halo)
@@ -581,6 +603,8 @@ int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t bufl
     snprintf(buf, buflen, "dense_layer_kernel");
   else if (o.kind == OP_LTAIL)
     snprintf(buf, buflen, "linknet_tail_kernel");
+  else if (o.kind == OP_FPNHEAD)
+    snprintf(buf, buflen, "fpn_head_kernel");
   else
     snprintf(buf, buflen, "%s", names[o.kind]);
   return MISEG_OK;

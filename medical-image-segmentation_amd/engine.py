@@ -473,6 +473,29 @@ class Engine:
         nbytes = x.n * x.h * x.w * 64 * 2 + self.n * self.h * self.wd * c * 5
         self._add(self.lib.miseg_plan_add_linknet_tail(self.plan, C.byref(d)), "decoder_stage4+final_conv", nbytes)
 
+    def _fpn_head(self, x):
+        """final_upsampling (bilinear x2) + head_conv + activation + collapse as one kernel: the
+        up-sampled 128-channel tensor (256 bytes per output pixel) never reaches HBM."""
+        d = L.FpnHeadDesc()
+        d.inp = x.ptr
+        k = self.w["head_conv"]["kernel"]                       # (3, 3, 128, classes)
+        wd = np.zeros((16, 9, 128), np.float32)
+        wd[:self.classes] = k.transpose(3, 0, 1, 2).reshape(self.classes, 9, 128)
+        d.wd = self.dev_h16(wd)
+        d.bias = self.dev_f32(self.w["head_conv"]["bias"])
+        d.out, d.collapse_out = self.probs.data_ptr(), self.mask.data_ptr()
+        d.N, d.H, d.W = x.n, x.h, x.w
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = x.pix, x.row, x.img
+        c = self.classes
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = c, c * self.wd, c * self.wd * self.h
+        d.classes = c
+        d.act = L.ACT_SIGMOID if self.g.activation == "sigmoid" else L.ACT_SOFTMAX
+        d.temperature = self.g.temperature if self.g.temperature is not None else 1.0
+        d.collapse_value = self.collapse_value
+        d.fmt = self.fmt
+        nbytes = x.n * x.h * x.w * 128 * 2 + self.n * self.h * self.wd * c * 5
+        self._add(self.lib.miseg_plan_add_fpn_head(self.plan, C.byref(d)), "final_upsampling+head_conv", nbytes)
+
     def _lower(self):
         g = self.g
         enc, dec = g.encoder, g.decoder
@@ -562,10 +585,14 @@ class Engine:
                         self.plan, s.ptr, None, dst.ptr, self.n, s.h, s.w, 128, shift, s.pix, 0,
                         dst.pix), "upsampling_stage%d" % st)
             x = self.conv_bn_relu("final_stage", agg, 3)
-            up = self.buf(2 * x.h, 2 * x.w, 128)
-            self._add(self.lib.miseg_plan_add_upsample_bilinear2x(
-                self.plan, x.ptr, up.ptr, self.n, x.h, x.w, 128, x.pix, up.pix), "final_upsampling")
-            self._head("head_conv", up)
+            if self.fuse_tail and x.c == 128 and self.classes <= 4 and \
+                    self.w["head_conv"]["kernel"].shape[:3] == (3, 3, 128):
+                self._fpn_head(x)
+            else:
+                up = self.buf(2 * x.h, 2 * x.w, 128)
+                self._add(self.lib.miseg_plan_add_upsample_bilinear2x(
+                    self.plan, x.ptr, up.ptr, self.n, x.h, x.w, 128, x.pix, up.pix), "final_upsampling")
+                self._head("head_conv", up)
         self.num_ops = self.lib.miseg_plan_num_ops(self.plan)
 
     # ---------------------------------------------------------------- running

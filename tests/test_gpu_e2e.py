@@ -33,6 +33,8 @@ CONFIGS = [
     ("densenet121", "U-Net", (64, 64), 1, 3),
     ("resnet18", "Linknet", (96, 160), 2, 1),  # fused tail: ragged 8x64 output patches, sigmoid head
     ("resnet34", "Linknet", (64, 128), 1, 4),  # fused tail: whole patches (vector stores), four classes
+    ("resnet18", "FPN", (96, 160), 1, 1),      # fused up-sampling + head: whole and ragged patches, sigmoid
+    ("resnet34", "FPN", (64, 96), 2, 4),       # four classes
 ]
 
 
@@ -120,6 +122,7 @@ def test_layerwise_forms_of_fused_kernels():
     check_engine("resnet18", "Linknet", (96, 160), 2, 3, fuse_tail=False)
     check_engine("densenet121", "Linknet", (64, 96), 1, 3, fuse_tail=False, fuse_dense=False)
     check_engine("resnet18", "U-Net", (64, 96), 2, 3, fuse_tail=False)
+    check_engine("resnet18", "FPN", (96, 160), 1, 3, fuse_tail=False)
 
 
 def check_engine(enc, dec, hw, n, classes, **engine_options):
