@@ -78,7 +78,7 @@ def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
 def pmc_traffic(kernel, batch, h, w, encoder, decoder):
     """HBM bytes per launch of `kernel` from the committed counter passes (collected with the same
     command at batch 4, 1920x2560, ResNet-34 U-Net); None for any other configuration."""
-    path = os.path.join(ROOT, "profiles", "r01_k_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_b_pmc_traffic.json")
     if not os.path.isfile(path) or (batch, h, w, encoder, decoder) != (4, 1920, 2560, "resnet34", "U-Net"):
         return None
     with open(path) as f:
@@ -179,6 +179,85 @@ def train_roofline(prof, ms_per_step):
     return head
 
 
+def extra_config(encoder, decoder, classes, h, w, batch, streams, dev, storage, steps=6, warmup=2):
+    """One more inference configuration of BASELINE.json (the DenseNet-169 models), measured the
+    same way as the headline one on this rank's GPU: images/s over `steps` steps of `streams`
+    concurrent plans of `batch` images, the dominant kernel's roofline from per-launch HIP events,
+    and the whole pass against the HBM peak with the algorithmic bytes of its convolution layers
+    (operands read once, results written once)."""
+    from miseg_amd import engine, netspec
+    graph = netspec.build_graph(encoder, decoder, (h, w, 3), classes)
+    weights = build_weights(graph)
+    engs = [engine.Engine(graph, weights, batch=batch, device=str(dev), storage=storage) for _ in range(streams)]
+    strs = [torch.cuda.Stream(dev) for _ in range(streams)]
+    for i, e in enumerate(engs):
+        e.x_in.copy_(torch.from_numpy(synthetic_images(batch, h, w, seed=4321 + i)).to(dev))
+    torch.cuda.synchronize()
+
+    def step():
+        for e, st in zip(engs, strs):
+            with torch.cuda.stream(st):
+                e.run()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    eng = engs[0]
+    nops = eng.num_ops
+    op_ms = np.zeros(nops)
+    for _ in range(3):
+        for i in range(nops):
+            op_ms[i] += eng.time_ops(i, i + 1)
+    op_ms /= 3
+    macs = np.array([eng.op_macs(i) for i in range(nops)], dtype=np.float64)
+    kernels = [eng.op_kernel(i) for i in range(nops)]
+    groups = {}
+    for i in range(nops):
+        g = groups.setdefault(kernels[i], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        g["launches"] += 1
+        g["ms"] += op_ms[i]
+        g["flops"] += 2.0 * macs[i]
+        g["bytes"] += eng.op_bytes[i]
+    dom_name = max(groups, key=lambda k: groups[k]["ms"])
+    dom = groups[dom_name]
+    ips = batch * streams * steps / elapsed
+    conv = macs > 0
+    gbytes_img = sum(eng.op_bytes) / batch / 1e9
+    gflop_img = 2.0 * macs.sum() / batch / 1e9
+    enc_names = {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "densenet169": "DenseNet-169"}
+    out = {
+        "metric": "images/sec at %dx%dx3 %s %s inference" % (h, w, enc_names.get(encoder, encoder), decoder),
+        "value": ips, "unit": "images/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps, "dtype": storage,
+        "config": {"workload": "%s %s inference %dx%dx3, %d classes, random-init weights, %d concurrent plan(s) of %d "
+                               "images, %s storage" % (encoder, decoder, h, w, classes, streams, batch, storage)},
+        "roofline": {
+            "bound": "mfma", "kernel": dom_name, "launches_per_step": dom["launches"],
+            "avg_launch_ms": dom["ms"] / dom["launches"],
+            "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
+            "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "share_of_pass": dom["ms"] / op_ms.sum(), "traffic": None,
+            "timing": "HIP events on the launch stream, one plan at a time (averaged over 3 passes)",
+            "all_conv_launches": {"achieved": 2.0 * macs.sum() / (op_ms[conv].sum() * 1e-3) / 1e12,
+                                  "frac": 2.0 * macs.sum() / (op_ms[conv].sum() * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                                  "ms_per_pass": float(op_ms[conv].sum()),
+                                  "non_conv_ms_per_pass": float(op_ms[~conv].sum())},
+            "whole_pass": {"gflop_per_image": gflop_img, "algorithmic_gbytes_per_image": gbytes_img,
+                           "mfma_frac": ips * gflop_img / 1e3 / MFMA_BF16_PEAK_TFLOPS,
+                           "hbm_frac": ips * gbytes_img / HBM_PEAK_GBS,
+                           "launches_per_pass": int(nops)},
+        },
+    }
+    del engs, eng
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +274,8 @@ def main():
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training leg")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the DenseNet-169 LinkNet / FPN inference lines (the `configs` array)")
     ap.add_argument("--train-encoder", default="resnet18")
     ap.add_argument("--train-batch", type=int, default=16, help="training images per GPU per step")
     ap.add_argument("--train-steps", type=int, default=5)
@@ -347,7 +428,7 @@ def main():
                 "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": pmc_traffic(dom_name, args.batch, h, w, args.encoder, args.decoder),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes), "
-                                "from the committed PMC passes profiles/r01_k_pmc_*.csv",
+                                "from the committed PMC passes profiles/r02_b_pmc_*.csv",
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                 "all_conv_launches": {
                     "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
@@ -358,6 +439,15 @@ def main():
         }
         if train is not None:
             result["train"] = train
+        if not args.no_extra and (args.encoder, args.decoder) == ("resnet34", "U-Net"):
+            # BASELINE.json configs 4 and 5's models, on this rank's GPU (their own lines; `value` above
+            # is the headline configuration only)
+            del engs, eng
+            torch.cuda.empty_cache()
+            result["configs"] = [
+                extra_config("densenet169", "Linknet", args.classes, h, w, 8, 2, dev, args.storage),
+                extra_config("densenet169", "FPN", args.classes, h, w, 4, 2, dev, args.storage),
+            ]
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.encoder, args.decoder, args.classes, h, w, weights)
         print(json.dumps(result), flush=True)

@@ -146,6 +146,10 @@ typedef struct miseg_conv_desc {
                             Add([relu(bn(conv)), skip]) of the LinkNet decoder blocks
                             (segmentation_models DecoderBlock, reached from utils/model.py:188-198),
                             instead of out = act(v + residual); needs residual, no out2 */
+  int32_t res_upsample_shift; /* s > 0: the residual tensor has extent (Ho >> s, Wo >> s) and is read at
+                                 [n, oy >> s, ox >> s, co]: UpSampling2D(2^s, 'nearest') + Add in the
+                                 epilogue, the top-down path of the FPN blocks (segmentation_models
+                                 FPNBlock, reached from utils/model.py:200-211) */
 } miseg_conv_desc;
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);

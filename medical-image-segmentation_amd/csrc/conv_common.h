@@ -55,6 +55,7 @@ struct ConvParams {
   int tiles_y, tiles_x;  // halo kernel: output patches per image
   double* stats;         // optional per-channel sum / sum of squares of the stored bf16 output
   int stats_rep, stats_stride;
+  int res_shift;         // the residual is read at (oy >> res_shift, ox >> res_shift): nearest up-sampling
   int res_after;         // the residual is added after the activation (out = act(v) + residual)
   int dgrad_t;           // data gradient of Conv2DTranspose(4, 2): `in` is dY, taps run over its four phase lattices
 };
@@ -256,8 +257,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
                               (long long)ox * p.out_pix_stride + cox;
       const long long o2_off = n * p.out2_img_stride + (long long)oy * p.out2_row_stride +
                                (long long)ox * p.out2_pix_stride + cox;
-      const long long r_off = n * p.res_img_stride + (long long)oy * p.res_row_stride +
-                              (long long)ox * p.res_pix_stride + cox;
+      const long long r_off = n * p.res_img_stride + (long long)(oy >> p.res_shift) * p.res_row_stride +
+                              (long long)(ox >> p.res_shift) * p.res_pix_stride + cox;
       if (fullx) {
         if (p.scale) {
           const float4 s0 = *reinterpret_cast<const float4*>(p.scale + cox);
@@ -569,8 +570,8 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const 
       o_off[i] = n * p.out_img_stride + (long long)oy * p.out_row_stride + (long long)ox * p.out_pix_stride;
       o2_off[i] = n * p.out2_img_stride + (long long)oy * p.out2_row_stride + (long long)ox * p.out2_pix_stride;
       if (has_res) {
-        const long long r_off = n * p.res_img_stride + (long long)oy * p.res_row_stride +
-                                (long long)ox * p.res_pix_stride;
+        const long long r_off = n * p.res_img_stride + (long long)(oy >> p.res_shift) * p.res_row_stride +
+                                (long long)(ox >> p.res_shift) * p.res_pix_stride;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
           res[i][q] = okp[i] && d.okc[q]

@@ -726,6 +726,8 @@ int validate_conv(const miseg_conv_desc* d) {
   } else if (d->out2) {
     MISEG_CHECK_ARG(d->scale2 && d->shift2, "conv: out2 needs scale2/shift2");
   }
+  MISEG_CHECK_ARG(d->res_upsample_shift >= 0 && d->res_upsample_shift <= 4 && (!d->res_upsample_shift || d->residual),
+                  "conv: res_upsample_shift must be 0..4 and needs a residual");
   if (d->res_after_act)
     MISEG_CHECK_ARG(d->residual && !d->out2 && d->act != MISEG_ACT_SOFTMAX && d->act != MISEG_ACT_SIGMOID,
                     "conv: res_after_act needs a residual, no second output and no head activation");
@@ -887,6 +889,7 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.M = d->N * d->Ho * d->Wo;
   p.dgrad_t = 0;
   p.res_after = d->res_after_act ? 1 : 0;
+  p.res_shift = d->res_upsample_shift;
   auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
     return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
   };

@@ -193,7 +193,7 @@ class Engine:
     def conv(self, name, x, wptr, cout, k, stride=1, pad=0, out=None, out_dtype=L.DT_BF16,
              scale=None, shift=None, act=L.ACT_NONE, residual=None, out2=None, scale2=None,
              shift2=None, in_scale=None, in_shift=None, transposed=False, collapse=None,
-             temperature=1.0, tile_hint=0, build_only=False, res_after=False):
+             temperature=1.0, tile_hint=0, build_only=False, res_after=False, res_shift=0):
         d = L.ConvDesc()
         cin = _ceil32(x.c)
         if x.c0 + cin > x.ctot:
@@ -216,7 +216,8 @@ class Engine:
         d.in_pix_stride, d.in_row_stride, d.in_img_stride = x.pix, x.row, x.img
         for v, pre in ((out, "out"), (out2, "out2"), (residual, "res")):
             if v is not None:
-                assert (v.h, v.w) == (oh, ow) and v.c >= cout, (name, pre, v.h, v.w, v.c, oh, ow, cout)
+                sh = res_shift if pre == "res" else 0
+                assert (v.h, v.w) == (oh >> sh, ow >> sh) and v.c >= cout, (name, pre, v.h, v.w, v.c, oh, ow, cout)
                 setattr(d, pre + "_pix_stride", v.pix)
                 setattr(d, pre + "_row_stride", v.row)
                 setattr(d, pre + "_img_stride", v.img)
@@ -242,6 +243,7 @@ class Engine:
         d.tile_hint = tile_hint
         d.fmt = self.fmt
         d.res_after_act = 1 if res_after else 0
+        d.res_upsample_shift = res_shift
         pix_out = x.n * oh * ow
         nbytes = x.n * x.h * x.w * x.c * 2 + cout * d.KH * d.KW * cin * 2 * (4 if transposed else 1)
         if out is not None:
@@ -564,11 +566,9 @@ class Engine:
                 lat = "fpn_stage_p%d_conv" % st
                 sk = skips[j]
                 p = self.buf(sk.h, sk.w, 256)
-                self.conv(lat, sk, self.conv_weight(lat), 256, 1, out=p, shift=self.w[lat]["bias"])
-                # p += nearest_upsample_x2(x)
-                self._add(self.lib.miseg_plan_add_upsample_nearest(
-                    self.plan, x.ptr, p.ptr, p.ptr, self.n, x.h, x.w, 256, 1, x.pix, p.pix, p.pix),
-                    "fpn_stage_p%d_add" % st)
+                # p = lateral(skip) + nearest_upsample_x2(x): the add in the convolution's epilogue
+                self.conv(lat, sk, self.conv_weight(lat), 256, 1, out=p, shift=self.w[lat]["bias"],
+                          residual=x, res_shift=1)
                 self.taps["fpn_stage_p%d_add" % st] = p
                 pyr.append(p)
                 x = p

@@ -17,9 +17,10 @@ def per_kernel(path, counter):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
-        if r["Counter_Name"] != counter or "miseg::" not in name:
+        if r["Counter_Name"] != counter or ("miseg::" not in name and "miseg_f16::" not in name):
             continue
-        name = name.replace("void ", "").replace("miseg::", "").split("(")[0]
+        # the fp16-storage compilation of a kernel (namespace miseg_f16) is reported under the same name
+        name = name.replace("void ", "").replace("miseg_f16::", "").replace("miseg::", "").split("(")[0]
         acc[name].append(float(r["Counter_Value"]))
     return acc
 

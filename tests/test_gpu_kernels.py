@@ -78,7 +78,7 @@ def dev_f32(a, dev):
 
 def run_conv(env, x, w_hwio, stride=1, pad=0, scale=None, shift=None, act=0, residual=None,
              res_f32=True, scale2=None, shift2=None, in_scale=None, in_shift=None, out_f32=False,
-             want_out=True, tile_hint=0, in_extra_c=0, out_extra_c=0, res_after=False):
+             want_out=True, tile_hint=0, in_extra_c=0, out_extra_c=0, res_after=False, res_shift=0):
     """x: (N,H,W,Cin) fp32 (bf16-representable); returns (out, out2) as fp32 numpy."""
     L, lib, dev = env
     n, h, wd, cin = x.shape
@@ -122,7 +122,9 @@ def run_conv(env, x, w_hwio, stride=1, pad=0, scale=None, shift=None, act=0, res
         keep.append(r)
         d.residual = r.data_ptr()
         d.res_dtype = L.DT_F32 if res_f32 else L.DT_BF16
-        d.res_pix_stride, d.res_row_stride, d.res_img_stride = cout, cout * wo, cout * wo * ho
+        rh, rw = r.shape[1], r.shape[2]
+        d.res_pix_stride, d.res_row_stride, d.res_img_stride = cout, cout * rw, cout * rw * rh
+        d.res_upsample_shift = res_shift
     d.scale, d.shift = f32p(scale), f32p(shift)
     d.in_scale, d.in_shift = f32p(in_scale), f32p(in_shift)
     d.act = act
@@ -208,6 +210,27 @@ def test_conv_residual_after_activation(env, shape, res_f32):
     # the pre-activation form differs wherever the convolution's value is negative
     pre, _ = run_conv(env, x, wt, 1, k // 2, scale=sc, shift=sh, act=1, residual=res, res_f32=res_f32, out_f32=True)
     np.testing.assert_allclose(pre, np.maximum(base * sc + sh + res, 0), rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 256), (3, 64, 128), (1, 96, 40)])
+@pytest.mark.parametrize("res_f32", [False, True])
+def test_conv_residual_upsampled(env, shape, res_f32):
+    """out = conv + bias + nearest_upsample_x2(residual): the top-down Add of the FPN blocks
+    (segmentation_models FPNBlock, /root/reference utils/model.py:200-211) in the epilogue."""
+    k, cin, cout = shape
+    rng = np.random.default_rng(cin + cout + k)
+    n, h, w = 2, 12, 38
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    wt = bf16_round(rng.normal(0, 0.1, (k, k, cin, cout)))
+    sh = rng.normal(0, 0.5, cout).astype(np.float32)
+    res = rng.normal(0, 1, (n, h // 2, w // 2, cout)).astype(np.float32)
+    if not res_f32:
+        res = bf16_round(res)
+    want = ref_conv(x, wt, 1, k // 2) + sh + np.repeat(np.repeat(res, 2, axis=1), 2, axis=2)
+    for out_f32 in (False, True):
+        got, _ = run_conv(env, x, wt, 1, k // 2, shift=sh, residual=res, res_f32=res_f32, out_f32=out_f32, res_shift=1)
+        tol = 1e-4 if out_f32 else 1e-2
+        np.testing.assert_allclose(got, want, rtol=tol, atol=tol * np.abs(want).max())
 
 
 def test_conv_epilogues(env):
