@@ -55,6 +55,7 @@ struct ConvParams {
   int tiles_y, tiles_x;  // halo kernel: output patches per image
   double* stats;         // optional per-channel sum / sum of squares of the stored bf16 output
   int stats_rep, stats_stride;
+  int direct;            // generic kernels: finish large launches with the LDS-free epilogue
   int res_shift;         // the residual is read at (oy >> res_shift, ox >> res_shift): nearest up-sampling
   int res_after;         // the residual is added after the activation (out = act(v) + residual)
   int dgrad_t;           // data gradient of Conv2DTranspose(4, 2): `in` is dY, taps run over its four phase lattices
