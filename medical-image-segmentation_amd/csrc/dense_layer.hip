@@ -71,11 +71,23 @@ __device__ __forceinline__ void dl_dma16(const void* src, void* lds_dst) {
 }
 }  // namespace
 
+#ifdef MISEG_DL_PROFILE
+// phase timers of wave w of block b (100 MHz ticks): [0] coefficients + first stages issued, [1] the 1x1's
+// chunk loop, [2] barrier + tile write, [3] the 3x3's tap loop, [4] exchange + stores
+__device__ unsigned long long g_dl_prof[1 << 16][8];
+#define DL_TICK(i) do { const unsigned long long t__ = wall_clock64(); dl_t[i] += t__ - dl_last; dl_last = t__; } while (0)
+#else
+#define DL_TICK(i) do { } while (0)
+#endif
+
 // c1: the 1x1 convolution (in = concatenation buffer, Cin = C, in_scale/in_shift = the first
 // BatchNorm, weight [128][C], scale/shift = the second BatchNorm, ReLU); c2: the 3x3 convolution
 // (weight [32][3][3][128], out = the 32 new channels).
 __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const ConvParams p, const ConvParams q) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[DL_LDS];
+#ifdef MISEG_DL_PROFILE
+  unsigned long long dl_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dl_last = wall_clock64();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const ConvParams p,
 
     issue_stage(0, 0);
     if (nch > 1) issue_stage(1, 1);
+    DL_TICK(0);
     int slot = 0;
     for (int ch = 0; ch < nch; ++ch) {
       if (ch + 1 < nch) dl_vmcnt<5>(); else dl_vmcnt<0>();
@@ -248,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const ConvParams p,
       slot = slot == 2 ? 0 : slot + 1;
     }
   }
+  DL_TICK(1);
   dl_barrier();          // every wave is done with the ring: the tile and the tap ring overlay it
   issue_w2(0, 0);
   issue_w2(1, 1);
@@ -298,6 +312,7 @@ __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const ConvParams p,
     });
   }
 
+  DL_TICK(2);
   // =============================== C: the 3x3 convolution ===============================
   const int rp = wave >> 1, kh = wave & 1;
   f32x16 oacc[2];
@@ -334,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const ConvParams p,
       });
     });
   }
+  DL_TICK(3);
   // no LDS-DMA is pending any more: plain LDS accesses and __syncthreads from here on
   __syncthreads();
   {
@@ -364,6 +380,12 @@ __global__ __launch_bounds__(256, 2) void dense_layer_kernel(const ConvParams p,
     const uint4 nores[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     direct_tile(q, dl, fin, okp, o_off, 0, false, nores, nullptr, nullptr, false);
   }
+#ifdef MISEG_DL_PROFILE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // count the stores' round trip
+  DL_TICK(4);
+  if (lane == 0 && blockIdx.x < (1 << 14))
+    for (int i = 0; i < 8; ++i) g_dl_prof[blockIdx.x * 4 + wave][i] = dl_t[i];
+#endif
 }
 
 hipError_t launch_dense_layer_kernel(const ConvParams& c1, const ConvParams& c2, dim3 grid, hipStream_t s) {
