@@ -122,7 +122,9 @@ def training_leg(args, dev, rank, world, dist, h, w):
     roof = train_roofline(tr.profile_step(x, gt), 1e3 * elapsed / args.train_steps) if rank == 0 else None
     del tr, x, gt
     torch.cuda.empty_cache()
-    return {"metric": "images/sec at 1920x2560x3 ResNet-18 U-Net training",
+    enc_names = {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "densenet169": "DenseNet-169"}
+    return {"metric": "images/sec at %dx%dx3 %s %s training" % (h, w, enc_names.get(args.train_encoder, args.train_encoder),
+                                                                 args.decoder),
             "value": args.train_batch * world * args.train_steps / elapsed, "unit": "images/s",
             "ms_per_step": 1e3 * elapsed / args.train_steps, "steps": args.train_steps,
             "warmup": args.train_warmup, "scaling": "weak",
@@ -352,8 +354,14 @@ def main():
         elapsed = float(t.item())
 
     train = None
+    train5 = None
     if not args.no_train:
         train = training_leg(args, dev, rank, world, dist, h, w)
+        if not args.no_extra and (args.encoder, args.decoder) == ("resnet34", "U-Net"):
+            # BASELINE.json config 5: DenseNet-169 FPN training (Dice loss, data parallel), 4 images per GPU
+            a5 = argparse.Namespace(**vars(args))
+            a5.train_encoder, a5.decoder, a5.train_batch, a5.train_steps, a5.train_warmup = "densenet169", "FPN", 4, 3, 1
+            train5 = training_leg(a5, dev, rank, world, dist, h, w)
 
     result = None
     if rank == 0:
@@ -439,6 +447,8 @@ def main():
         }
         if train is not None:
             result["train"] = train
+        if train5 is not None:
+            result["train_configs"] = [train5]
         if not args.no_extra and (args.encoder, args.decoder) == ("resnet34", "U-Net"):
             # BASELINE.json configs 4 and 5's models, on this rank's GPU (their own lines; `value` above
             # is the headline configuration only)
