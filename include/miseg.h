@@ -536,6 +536,22 @@ int miseg_augment(const float* img, const float* mask, float* img_out, float* ma
                   void* stream);
 
 /*
+ * Gradient all-reduce of data-parallel training: what tf.distribute.MultiWorkerMirroredStrategy does
+ * for the reference at model_train.py:272-301 (one replica per GPU, gradients summed over replicas
+ * every step), on RCCL over xGMI, one process per GPU.  RCCL is loaded at run time on the first of
+ * these calls.  Rank 0 obtains a 128-byte id with miseg_comm_unique_id and hands it to the other
+ * ranks by any means; every rank then calls miseg_comm_init with the device it will use current.
+ * miseg_allreduce_async sums `count` floats in place over all ranks, asynchronously on `stream`
+ * (launch it on a communication stream as soon as a bucket of the flat gradient buffer is final, so
+ * that it overlaps the rest of the backward pass); all ranks must issue the same sequence of calls.
+ */
+typedef struct miseg_comm miseg_comm;
+int miseg_comm_unique_id(void* id128);
+int miseg_comm_init(miseg_comm** comm, int32_t rank, int32_t world, const void* id128);
+int miseg_allreduce_async(miseg_comm* comm, float* buf, int64_t count, void* stream);
+int miseg_comm_destroy(miseg_comm* comm);
+
+/*
  * A plan is a recorded list of the calls above with fixed arguments, replayed
  * with one call per forward pass (the analogue of the compiled tf.function
  * behind model(batch, training=False), utils/predict.py:159).

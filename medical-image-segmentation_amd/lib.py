@@ -146,6 +146,10 @@ SIGNATURES = {
     "miseg_resize_nearest_u8": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_one_hot": (C.c_int, [_VP, _FP, _I64, _I32, _VP]),
     "miseg_augment": (C.c_int, [_FP, _FP, _FP, _FP, _I32, _I32, _I32, _I32, _FP, _VP, _VP]),
+    "miseg_comm_unique_id": (C.c_int, [_VP]),
+    "miseg_comm_init": (C.c_int, [C.POINTER(_VP), _I32, _I32, _VP]),
+    "miseg_allreduce_async": (C.c_int, [_VP, _FP, _I64, _VP]),
+    "miseg_comm_destroy": (C.c_int, [_VP]),
     "miseg_plan_create": (_VP, []),
     "miseg_plan_destroy": (None, [_VP]),
     "miseg_plan_num_ops": (C.c_int, [_VP]),
