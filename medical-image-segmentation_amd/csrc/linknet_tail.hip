@@ -125,57 +125,104 @@ __global__ __launch_bounds__(256, 3) void linknet_tail_kernel(const TailParams t
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- 1: 1x1 64 -> 16 on the input tile ----
-  for (int tl = wave; tl < (LT_HPX + 15) / 16; tl += 4) {
-    const int px = tl * 16 + row;
-    const int pc = px < LT_HPX ? px : LT_HPX - 1;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      acc = mfma_16x16x32(fa[ks], *reinterpret_cast<const h16x8*>(XH + pc * LT_XPITCH + ks * 64 + kg * 16), acc);
-    const int hy = pc / LT_HW, hx = pc - hy * LT_HW;
-    const bool inside = (unsigned)(y0 - 1 + hy) < (unsigned)t.H && (unsigned)(x0 - 1 + hx) < (unsigned)t.W;
-    uint2 o = lt_pack4(h16_relu(acc[0] * sa4.x + ta4.x), h16_relu(acc[1] * sa4.y + ta4.y),
-                       h16_relu(acc[2] * sa4.z + ta4.z), h16_relu(acc[3] * sa4.w + ta4.w));
-    if (!inside) o = make_uint2(0, 0);
-    if (px < LT_HPX) *reinterpret_cast<uint2*>(MA + px * LT_MPITCH + kg * 8) = o;
-  }
-  __syncthreads();
+  // Every phase below reads all of a wave's fragments first, then runs its matrix instructions, then
+  // writes: the loads of different tiles are independent, but the compiler cannot move an LDS read
+  // above an earlier LDS write of the same array, so a tile-by-tile loop would expose the LDS
+  // latency once per tile.
 
-  // ---- 2: the transpose, phase (a, b) = wave ----
+  // ---- 1: 1x1 64 -> 16 on the input tile (13 tiles of 16 pixels: wave, wave + 4, ...) ----
   {
-    const int pa = wave >> 1, pb = wave & 1;
-    for (int tl = 0; tl < (LT_PPX + 15) / 16; ++tl) {
-      const int p = tl * 16 + row;
-      const int pc = p < LT_PPX ? p : LT_PPX - 1;
-      const int r = pc / LT_PW, c = pc - r * LT_PW;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int NT1 = ((LT_HPX + 15) / 16 + 3) / 4;
+    h16x8 xb[NT1][2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)      // taps (dy, dx) = (ks, kg >> 1), channels 8 (kg & 1) ..
-        acc = mfma_16x16x32(fb[ks], *reinterpret_cast<const h16x8*>(
-                                        MA + ((r + ks) * LT_HW + c + (kg >> 1)) * LT_MPITCH + (kg & 1) * 16), acc);
-      const uint2 o = lt_pack4(h16_relu(acc[0] * sb4.x + tb4.x), h16_relu(acc[1] * sb4.y + tb4.y),
-                               h16_relu(acc[2] * sb4.z + tb4.z), h16_relu(acc[3] * sb4.w + tb4.w));
-      if (p < LT_PPX)
-        *reinterpret_cast<uint2*>(BC + ((2 * r - pa + 1) * LT_OW + (2 * c - pb + 1)) * LT_MPITCH + kg * 8) = o;
+    for (int k = 0; k < NT1; ++k) {
+      const int px = (wave + 4 * k) * 16 + row;
+      const int pc = px < LT_HPX ? px : LT_HPX - 1;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        xb[k][ks] = *reinterpret_cast<const h16x8*>(XH + pc * LT_XPITCH + ks * 64 + kg * 16);
+    }
+    f32x4 acc[NT1];
+#pragma unroll
+    for (int k = 0; k < NT1; ++k) {
+      acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) acc[k] = mfma_16x16x32(fa[ks], xb[k][ks], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < NT1; ++k) {
+      const int px = (wave + 4 * k) * 16 + row;
+      const int pc = px < LT_HPX ? px : LT_HPX - 1;
+      const int hy = pc / LT_HW, hx = pc - hy * LT_HW;
+      const bool inside = (unsigned)(y0 - 1 + hy) < (unsigned)t.H && (unsigned)(x0 - 1 + hx) < (unsigned)t.W;
+      uint2 o = lt_pack4(h16_relu(acc[k][0] * sa4.x + ta4.x), h16_relu(acc[k][1] * sa4.y + ta4.y),
+                         h16_relu(acc[k][2] * sa4.z + ta4.z), h16_relu(acc[k][3] * sa4.w + ta4.w));
+      if (!inside) o = make_uint2(0, 0);
+      if (px < LT_HPX) *reinterpret_cast<uint2*>(MA + px * LT_MPITCH + kg * 8) = o;
     }
   }
   __syncthreads();
 
-  // ---- 3: 1x1 16 -> 16 in place ----
-  for (int tl = wave; tl < (LT_OPX + 15) / 16; tl += 4) {
-    const int p = tl * 16 + row;
-    const int pc = p < LT_OPX ? p : LT_OPX - 1;
-    h16x8 xb = *reinterpret_cast<const h16x8*>(BC + pc * LT_MPITCH + (kg & 1) * 16);
-    if (kg >= 2) xb = __builtin_bit_cast(h16x8, make_uint4(0, 0, 0, 0));
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = mfma_16x16x32(fc, xb, acc);
-    const int ry = pc / LT_OW, rx = pc - ry * LT_OW;
-    const bool inside = (unsigned)(Y0 - 1 + ry) < (unsigned)Ho && (unsigned)(X0 - 1 + rx) < (unsigned)Wo;
-    uint2 o = lt_pack4(h16_relu(acc[0] * sc4.x + tc4.x), h16_relu(acc[1] * sc4.y + tc4.y),
-                       h16_relu(acc[2] * sc4.z + tc4.z), h16_relu(acc[3] * sc4.w + tc4.w));
-    if (!inside) o = make_uint2(0, 0);
-    if (p < LT_OPX) *reinterpret_cast<uint2*>(BC + p * LT_MPITCH + kg * 8) = o;
+  // ---- 2: the transpose, phase (a, b) = wave: 11 tiles in two batches ----
+  {
+    const int pa = wave >> 1, pb = wave & 1;
+    constexpr int NT2 = (LT_PPX + 15) / 16, HB = (NT2 + 1) / 2;
+#pragma unroll
+    for (int h0 = 0; h0 < NT2; h0 += HB) {
+      h16x8 xb[HB][2];
+#pragma unroll
+      for (int k = 0; k < HB; ++k) {
+        const int p = (h0 + k) * 16 + row;
+        const int pc = p < LT_PPX ? p : LT_PPX - 1;
+        const int r = pc / LT_PW, c = pc - r * LT_PW;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)      // taps (dy, dx) = (ks, kg >> 1), channels 8 (kg & 1) ..
+          xb[k][ks] = *reinterpret_cast<const h16x8*>(MA + ((r + ks) * LT_HW + c + (kg >> 1)) * LT_MPITCH + (kg & 1) * 16);
+      }
+#pragma unroll
+      for (int k = 0; k < HB; ++k) {
+        if (h0 + k >= NT2) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = mfma_16x16x32(fb[ks], xb[k][ks], acc);
+        const int p = (h0 + k) * 16 + row;
+        const int pc = p < LT_PPX ? p : LT_PPX - 1;
+        const int r = pc / LT_PW, c = pc - r * LT_PW;
+        const uint2 o = lt_pack4(h16_relu(acc[0] * sb4.x + tb4.x), h16_relu(acc[1] * sb4.y + tb4.y),
+                                 h16_relu(acc[2] * sb4.z + tb4.z), h16_relu(acc[3] * sb4.w + tb4.w));
+        if (p < LT_PPX)
+          *reinterpret_cast<uint2*>(BC + ((2 * r - pa + 1) * LT_OW + (2 * c - pb + 1)) * LT_MPITCH + kg * 8) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3: 1x1 16 -> 16 in place (42 tiles: wave, wave + 4, ...) ----
+  {
+    constexpr int NT3 = ((LT_OPX + 15) / 16 + 3) / 4;
+    h16x8 xb[NT3];
+#pragma unroll
+    for (int k = 0; k < NT3; ++k) {
+      const int p = (wave + 4 * k) * 16 + row;
+      const int pc = p < LT_OPX ? p : LT_OPX - 1;
+      xb[k] = *reinterpret_cast<const h16x8*>(BC + pc * LT_MPITCH + (kg & 1) * 16);
+      if (kg >= 2) xb[k] = __builtin_bit_cast(h16x8, make_uint4(0, 0, 0, 0));
+    }
+    // (a tile past the end re-reads the last pixel, which another wave may already have rewritten:
+    // its result is not stored)
+#pragma unroll
+    for (int k = 0; k < NT3; ++k) {
+      const int p = (wave + 4 * k) * 16 + row;
+      const int pc = p < LT_OPX ? p : LT_OPX - 1;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mfma_16x16x32(fc, xb[k], acc);
+      const int ry = pc / LT_OW, rx = pc - ry * LT_OW;
+      const bool inside = (unsigned)(Y0 - 1 + ry) < (unsigned)Ho && (unsigned)(X0 - 1 + rx) < (unsigned)Wo;
+      uint2 o = lt_pack4(h16_relu(acc[0] * sc4.x + tc4.x), h16_relu(acc[1] * sc4.y + tc4.y),
+                         h16_relu(acc[2] * sc4.z + tc4.z), h16_relu(acc[3] * sc4.w + tc4.w));
+      if (!inside) o = make_uint2(0, 0);
+      if (p < LT_OPX) *reinterpret_cast<uint2*>(BC + p * LT_MPITCH + kg * 8) = o;
+    }
   }
   __syncthreads();
 
@@ -198,13 +245,20 @@ __global__ __launch_bounds__(256, 3) void linknet_tail_kernel(const TailParams t
   for (int rr = 0; rr < 2; ++rr) {
     const int orow = 2 * wave + rr;
     f32x4 hacc[4];
+    {
+      h16x8 xb[4][5];
 #pragma unroll
-    for (int tl = 0; tl < 4; ++tl) {
-      hacc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const unsigned char* base = BC + (orow * LT_OW + tl * 16 + row) * LT_MPITCH;
+      for (int tl = 0; tl < 4; ++tl) {
+        const unsigned char* base = BC + (orow * LT_OW + tl * 16 + row) * LT_MPITCH;
 #pragma unroll
-      for (int s = 0; s < 5; ++s)
-        hacc[tl] = mfma_16x16x32(fd[s], *reinterpret_cast<const h16x8*>(base + hoff[s]), hacc[tl]);
+        for (int s = 0; s < 5; ++s) xb[tl][s] = *reinterpret_cast<const h16x8*>(base + hoff[s]);
+      }
+#pragma unroll
+      for (int tl = 0; tl < 4; ++tl) {
+        hacc[tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 5; ++s) hacc[tl] = mfma_16x16x32(fd[s], xb[tl][s], hacc[tl]);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
