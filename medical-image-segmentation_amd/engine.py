@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import lib as L
-from .netspec import RESNET_UNITS, DENSENET_LAYERS
+from .netspec import RESNET_UNITS, RESNET_BOTTLENECK, DENSENET_LAYERS
 
 
 class View:
@@ -311,8 +311,11 @@ class Engine:
             self.dev_f32(shift) if shift is not None else None, x.n, x.h, x.w, x.c, x.pix, out.pix),
             name)
 
-    def _resnet(self, units, skip_dst):
-        """skip_dst: {layer_name: View} destinations for the four skip tensors."""
+    def _resnet(self, units, skip_dst, bottleneck=False):
+        """skip_dst: {layer_name: View} destinations for the four skip tensors.  Pre-activation
+        units: every BatchNorm + ReLU is the epilogue of the convolution that feeds it; the
+        convolution that closes a unit adds the shortcut, writes the raw sum (the next unit's
+        shortcut) and, as a second output, the next unit's bn1 + relu1 of it."""
         h2, w2 = self.h // 2, self.wd // 2
         relu0 = skip_dst.get("relu0") or self.buf(h2, w2, 64)
         self._stem("conv0", "bn0", "bn_data", relu0)
@@ -323,6 +326,7 @@ class Engine:
         self._maxpool(relu0, a, s, t, "pooling0")
         self.taps["stage1_unit1_relu1"] = a
         order = [(s_, b_) for s_, reps in enumerate(units) for b_ in range(reps)]
+        ex = 4 if bottleneck else 1
         xraw = None
         for idx, (stage, block) in enumerate(order):
             base = "stage%d_unit%d_" % (stage + 1, block + 1)
@@ -331,15 +335,26 @@ class Engine:
             ho, wo = a.h // stride, a.w // stride
             rdt, rdt_l = (self.tdtype, L.DT_BF16) if self.residual_bf16 else (torch.float32, L.DT_F32)
             if block == 0:
-                shortcut = self.buf(ho, wo, f, rdt)
-                self.conv(base + "sc", a, self.conv_weight(base + "sc"), f, 1, stride=stride,
+                shortcut = self.buf(ho, wo, f * ex, rdt)
+                self.conv(base + "sc", a, self.conv_weight(base + "sc"), f * ex, 1, stride=stride,
                           out=shortcut, out_dtype=rdt_l)
             else:
                 shortcut = xraw
             s, t = self.bn_fold(base + "bn2")
-            b1 = self.buf(ho, wo, f)
-            self.conv(base + "conv1", a, self.conv_weight(base + "conv1"), f, 3, stride=stride,
-                      pad=1, out=b1, scale=s, shift=t, act=L.ACT_RELU)
+            if bottleneck:      # 1x1 -> 3x3 (carries the stride) -> 1x1 to four times the filters
+                b1 = self.buf(a.h, a.w, f)
+                self.conv(base + "conv1", a, self.conv_weight(base + "conv1"), f, 1, out=b1, scale=s, shift=t,
+                          act=L.ACT_RELU)
+                s, t = self.bn_fold(base + "bn3")
+                b2 = self.buf(ho, wo, f)
+                self.conv(base + "conv2", b1, self.conv_weight(base + "conv2"), f, 3, stride=stride, pad=1,
+                          out=b2, scale=s, shift=t, act=L.ACT_RELU)
+                last_name, last_in, last_k = base + "conv3", b2, 1
+            else:
+                b1 = self.buf(ho, wo, f)
+                self.conv(base + "conv1", a, self.conv_weight(base + "conv1"), f, 3, stride=stride,
+                          pad=1, out=b1, scale=s, shift=t, act=L.ACT_RELU)
+                last_name, last_in, last_k = base + "conv2", b1, 3
             last = idx + 1 == len(order)
             if last:
                 nbn, nname, need_raw = "bn1", "relu1", False
@@ -349,9 +364,9 @@ class Engine:
                 nname = "stage%d_unit%d_relu1" % (ns + 1, nb + 1)
                 need_raw = nb != 0
             s2, t2 = self.bn_fold(nbn)
-            a_next = skip_dst.get(nname) or self.buf(ho, wo, f)
-            xraw = self.buf(ho, wo, f, rdt) if need_raw else None
-            self.conv(base + "conv2", b1, self.conv_weight(base + "conv2"), f, 3, pad=1,
+            a_next = skip_dst.get(nname) or self.buf(ho, wo, f * ex)
+            xraw = self.buf(ho, wo, f * ex, rdt) if need_raw else None
+            self.conv(last_name, last_in, self.conv_weight(last_name), f * ex, last_k, pad=(last_k - 1) // 2,
                       out=xraw, out_dtype=rdt_l, residual=shortcut, out2=a_next, scale2=s2,
                       shift2=t2)
             self.taps[nname] = a_next
@@ -517,7 +532,7 @@ class Engine:
                 if i < 4:
                     skip_dst[skip_names[i]] = cb.slice(f, sc)
         if enc in RESNET_UNITS:
-            x = self._resnet(RESNET_UNITS[enc], skip_dst)
+            x = self._resnet(RESNET_UNITS[enc], skip_dst, enc in RESNET_BOTTLENECK)
         else:
             x = self._densenet(DENSENET_LAYERS[enc], skip_dst)
         skips = [self.taps[n] for n in skip_names]

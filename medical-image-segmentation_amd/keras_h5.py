@@ -45,9 +45,9 @@ def infer_architecture(config):
         return n
     if "stage1_unit1_bn1" in nameset:
         units = tuple(count("stage%d_unit%%d_bn1" % s) for s in (1, 2, 3, 4))
-        if "stage1_unit1_conv3" in nameset:
-            raise ValueError("bottleneck ResNets (resnet50+) are not built here")
-        enc = {v: k for k, v in netspec.RESNET_UNITS.items()}.get(units)
+        bott = "stage1_unit1_conv3" in nameset      # resnet34 and resnet50 share their unit counts
+        enc = {v: k for k, v in netspec.RESNET_UNITS.items()
+               if (k in netspec.RESNET_BOTTLENECK) == bott}.get(units)
     elif "conv2_block1_0_bn" in nameset:
         blocks = tuple(count("conv%d_block%%d_0_bn" % s) for s in (2, 3, 4, 5))
         enc = {v: k for k, v in netspec.DENSENET_LAYERS.items()}.get(blocks)

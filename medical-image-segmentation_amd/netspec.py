@@ -1,5 +1,5 @@
 """Symbolic layer graphs of the networks `make_model` builds
-(/root/reference utils/model.py:175-211): encoders ResNet-18/34
+(/root/reference utils/model.py:175-211): encoders ResNet-18/34/50/101/152
 (classification_models) and DenseNet-121/169/201 (keras_applications), decoders
 U-Net, Linknet and FPN (segmentation_models) with the hyper-parameters the
 reference fixes.  A graph is an ordered list of Keras-style layer records
@@ -13,11 +13,18 @@ BACKBONE_FEATURES = {
     # segmentation_models Backbones._default_feature_layers (deep -> shallow)
     "resnet18": ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0"),
     "resnet34": ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0"),
+    "resnet50": ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0"),
+    "resnet101": ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0"),
+    "resnet152": ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0"),
     "densenet121": (311, 139, 51, 4),
     "densenet169": (367, 139, 51, 4),
     "densenet201": (479, 139, 51, 4),
 }
-RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3),
+                "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}
+# classification_models residual_bottleneck_block (1x1, 3x3, 1x1 to four times the filters) instead of
+# residual_conv_block (3x3, 3x3)
+RESNET_BOTTLENECK = ("resnet50", "resnet101", "resnet152")
 DENSENET_LAYERS = {"densenet121": (6, 12, 24, 16), "densenet169": (6, 12, 32, 32),
                    "densenet201": (6, 12, 48, 32)}
 
@@ -151,7 +158,7 @@ class Graph:
 # ---------------------------------------------------------------------------
 # encoders
 # ---------------------------------------------------------------------------
-def _resnet(g, x, units):
+def _resnet(g, x, units, bottleneck=False):
     eps = 2e-5
     he = "he_uniform"
     x = g.bn(x, "bn_data", eps, scale=False)
@@ -169,13 +176,24 @@ def _resnet(g, x, units):
             strides = 2 if (first and stage > 0) else 1
             y = g.bn(x, base + "bn1", eps)
             y = g.act(y, "relu", base + "relu1")
-            shortcut = g.conv(y, filters, 1, base + "sc", strides=strides, init=he) if first else x
-            y = g.zero_pad(y, 1)
-            y = g.conv(y, filters, 3, base + "conv1", strides=strides, init=he)
-            y = g.bn(y, base + "bn2", eps)
-            y = g.act(y, "relu", base + "relu2")
-            y = g.zero_pad(y, 1)
-            y = g.conv(y, filters, 3, base + "conv2", init=he)
+            if bottleneck:
+                shortcut = g.conv(y, 4 * filters, 1, base + "sc", strides=strides, init=he) if first else x
+                y = g.conv(y, filters, 1, base + "conv1", init=he)
+                y = g.bn(y, base + "bn2", eps)
+                y = g.act(y, "relu", base + "relu2")
+                y = g.zero_pad(y, 1)
+                y = g.conv(y, filters, 3, base + "conv2", strides=strides, init=he)
+                y = g.bn(y, base + "bn3", eps)
+                y = g.act(y, "relu", base + "relu3")
+                y = g.conv(y, 4 * filters, 1, base + "conv3", init=he)
+            else:
+                shortcut = g.conv(y, filters, 1, base + "sc", strides=strides, init=he) if first else x
+                y = g.zero_pad(y, 1)
+                y = g.conv(y, filters, 3, base + "conv1", strides=strides, init=he)
+                y = g.bn(y, base + "bn2", eps)
+                y = g.act(y, "relu", base + "relu2")
+                y = g.zero_pad(y, 1)
+                y = g.conv(y, filters, 3, base + "conv2", init=he)
             x = g.add([y, shortcut])
     x = g.bn(x, "bn1", eps)
     return g.act(x, "relu", "relu1")
@@ -287,7 +305,7 @@ def build_graph(encoder, decoder, input_shape, classes, activation=None, tempera
     g = Graph(name or "model")
     x = g.input(h, w, c, "data" if encoder in RESNET_UNITS else "input_1")
     if encoder in RESNET_UNITS:
-        x = _resnet(g, x, RESNET_UNITS[encoder])
+        x = _resnet(g, x, RESNET_UNITS[encoder], encoder in RESNET_BOTTLENECK)
     elif encoder in DENSENET_LAYERS:
         x = _densenet(g, x, DENSENET_LAYERS[encoder])
     else:

@@ -16,7 +16,9 @@ from collections import OrderedDict
 
 import numpy as np
 
-RESNET_REPS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3)}
+RESNET_REPS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (3, 4, 6, 3),
+               "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}
+RESNET_BOTTLENECK = ("resnet50", "resnet101", "resnet152")      # [UPSTREAM] residual_bottleneck_block
 DENSENET_BLOCKS = {"densenet169": (6, 12, 32, 32), "densenet121": (6, 12, 24, 16),
                    "densenet201": (6, 12, 48, 32)}
 RESNET_EPS = 2e-5
@@ -54,24 +56,32 @@ class Spec:
         self.layers[name] = ("bn", ws)
 
 
-def _resnet_spec(s, reps):
+def _resnet_spec(s, reps, bottleneck=False):
     s.bn("bn_data", 3, scale=False)
     s.conv("conv0", 7, 3, 64)
     s.bn("bn0", 64)
     cin = 64
+    ex = 4 if bottleneck else 1
     for stage, rep in enumerate(reps):
         f = 64 * 2 ** stage
         for block in range(rep):
             base = "stage%d_unit%d_" % (stage + 1, block + 1)
             s.bn(base + "bn1", cin)
             if block == 0:
-                s.conv(base + "sc", 1, cin, f)
-            s.conv(base + "conv1", 3, cin, f)
-            s.bn(base + "bn2", f)
-            s.conv(base + "conv2", 3, f, f)
-            cin = f
+                s.conv(base + "sc", 1, cin, f * ex)
+            if bottleneck:
+                s.conv(base + "conv1", 1, cin, f)
+                s.bn(base + "bn2", f)
+                s.conv(base + "conv2", 3, f, f)
+                s.bn(base + "bn3", f)
+                s.conv(base + "conv3", 1, f, 4 * f)
+            else:
+                s.conv(base + "conv1", 3, cin, f)
+                s.bn(base + "bn2", f)
+                s.conv(base + "conv2", 3, f, f)
+            cin = f * ex
     s.bn("bn1", cin)
-    return [256, 128, 64, 64], cin     # skip channels (deep -> shallow), output channels
+    return [256 * ex, 128 * ex, 64 * ex, 64], cin     # skip channels (deep -> shallow), output channels
 
 
 def _densenet_spec(s, blocks):
@@ -108,7 +118,7 @@ def build_spec(encoder, decoder, classes):
     (utils/model.py:145-236)."""
     s = Spec()
     if encoder in RESNET_REPS:
-        skips, c = _resnet_spec(s, RESNET_REPS[encoder])
+        skips, c = _resnet_spec(s, RESNET_REPS[encoder], encoder in RESNET_BOTTLENECK)
     elif encoder in DENSENET_BLOCKS:
         skips, c = _densenet_spec(s, DENSENET_BLOCKS[encoder])
     else:
@@ -221,7 +231,7 @@ class _Ctx:
         return self.tap(name + "_relu", self.ops.relu(x))
 
 
-def _resnet_forward(c, x, reps):
+def _resnet_forward(c, x, reps, bottleneck=False):
     ops = c.ops
     x = c.bn(x, "bn_data", RESNET_EPS)
     x = c.conv(x, "conv0", stride=2, pad=3)
@@ -240,13 +250,20 @@ def _resnet_forward(c, x, reps):
             else:
                 stride = 1
                 shortcut = x
-            y = c.conv(a, base + "conv1", stride=stride, pad=1)
-            y = ops.relu(c.bn(y, base + "bn2", RESNET_EPS))
-            y = c.conv(y, base + "conv2", stride=1, pad=1)
+            if bottleneck:      # 1x1 -> 3x3 (carries the stride) -> 1x1 to four times the filters
+                y = c.conv(a, base + "conv1", stride=1, pad=0)
+                y = ops.relu(c.bn(y, base + "bn2", RESNET_EPS))
+                y = c.conv(y, base + "conv2", stride=stride, pad=1)
+                y = ops.relu(c.bn(y, base + "bn3", RESNET_EPS))
+                y = c.conv(y, base + "conv3", stride=1, pad=0)
+            else:
+                y = c.conv(a, base + "conv1", stride=stride, pad=1)
+                y = ops.relu(c.bn(y, base + "bn2", RESNET_EPS))
+                y = c.conv(y, base + "conv2", stride=1, pad=1)
             x = c.tap(base + "add", ops.add(y, shortcut))
     x = ops.relu(c.bn(x, "bn1", RESNET_EPS))
     c.tap("relu1", x)
-    # sm Backbones feature layers for resnet18/34, deep -> shallow
+    # sm Backbones feature layers for the ResNets, deep -> shallow
     feats = [skips["stage4_unit1_relu1"], skips["stage3_unit1_relu1"],
              skips["stage2_unit1_relu1"], skips["relu0"]]
     return x, feats
@@ -339,7 +356,7 @@ def forward(ops, encoder, decoder, weights, x, activation="softmax", temperature
         c.batch_stats = batch_stats
     x = ops.asarray(x)
     if encoder in RESNET_REPS:
-        x, feats = _resnet_forward(c, x, RESNET_REPS[encoder])
+        x, feats = _resnet_forward(c, x, RESNET_REPS[encoder], encoder in RESNET_BOTTLENECK)
     else:
         x, feats = _densenet_forward(c, x, DENSENET_BLOCKS[encoder])
     if decoder == "U-Net":

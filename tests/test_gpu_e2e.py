@@ -35,6 +35,8 @@ CONFIGS = [
     ("resnet34", "Linknet", (64, 128), 1, 4),  # fused tail: whole patches (vector stores), four classes
     ("resnet18", "FPN", (96, 160), 1, 1),      # fused up-sampling + head: whole and ragged patches, sigmoid
     ("resnet34", "FPN", (64, 96), 2, 4),       # four classes
+    ("resnet50", "U-Net", (64, 96), 1, 3),     # bottleneck units (classification_models residual_bottleneck_block)
+    ("resnet50", "Linknet", (64, 64), 2, 3),
 ]
 
 
@@ -59,6 +61,13 @@ def test_engine_vs_oracle(enc, dec, hw, n, classes):
 @pytest.mark.parametrize("enc,dec,hw,n,classes", [CONFIGS[0], CONFIGS[1], CONFIGS[3], CONFIGS[4]])
 def test_engine_vs_oracle_bf16_storage(enc, dec, hw, n, classes):
     check_engine(enc, dec, hw, n, classes, storage="bf16")
+
+
+def test_deep_bottleneck_resnet_on_bf16_storage():
+    """ResNet-101 with seeded random weights (no training to keep the batch-norm scales in check) grows
+    its residual stream to ~1e6 over 33 units: beyond fp16's 65504, inside bf16's range.  The engine's
+    bf16 storage is the format for such a network; trained networks stay within a few tens."""
+    check_engine("resnet101", "FPN", (64, 64), 1, 3, storage="bf16")
 
 
 def headline_agreement(storage, h=1920, w=2560, want=None, x=None, weights=None):

@@ -34,6 +34,7 @@ CONFIGS = [
     ("densenet121", "FPN", 64, 64, 1),
     ("densenet169", "FPN", 64, 64, 1),          # BASELINE config 5's network
     ("densenet169", "Linknet", 64, 64, 1),      # the reference's preferred model
+    ("resnet50", "U-Net", 64, 64, 1),           # bottleneck units
 ]
 
 

@@ -80,7 +80,7 @@ def test_writer_reader_round_trip(pkg, tmp_path):
 
 
 @pytest.mark.parametrize("enc,dec,tss", [("resnet18", "U-Net", False), ("resnet34", "Linknet", True),
-                                         ("densenet121", "FPN", False)])
+                                         ("densenet121", "FPN", False), ("resnet50", "U-Net", False)])
 def test_keras_layout_round_trip(pkg, tmp_path, enc, dec, tss):
     from miseg_amd import keras_h5, netspec, h5io
     from miseg_amd.model import Model

@@ -69,7 +69,10 @@ def test_plan_records_and_validates_without_gpu(pkg):
 
 @pytest.mark.parametrize("enc,dec,total", [
     ("resnet18", "U-Net", 22903084), ("resnet34", "U-Net", 33018668),
-    ("densenet169", "Linknet", 17051571), ("densenet169", "FPN", 15716035)])
+    ("densenet169", "Linknet", 17051571), ("densenet169", "FPN", 15716035),
+    # bottleneck ResNets: the two independently written builders (graph, oracle spec) must agree; the
+    # totals are what they agree on, not published numbers
+    ("resnet50", "U-Net", 52490028), ("resnet101", "Linknet", 50266940), ("resnet152", "FPN", 61648204)])
 def test_graph_param_counts_and_oracle_spec(pkg, enc, dec, total):
     from miseg_amd import netspec
     from oracle import nets
