@@ -438,6 +438,28 @@ int miseg_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, int64_t pix
 int miseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
                            int32_t C, int32_t x_pix_stride, int32_t dy_pix_stride,
                            int32_t dx_pix_stride, void* stream);
+/* MaxPooling2D(2, strides=2) of the keras_applications VGG encoders (the block*_pool layers the reference
+ * reaches through sm.Unet/Linknet/FPN(backbone_name="vgg16"), /root/reference utils/model.py:176-211).
+ * in [N,H,W,C] -> out [N,H/2,W/2,C], 16-bit in storage format fmt; H, W even. */
+int miseg_maxpool2x2_fwd(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t in_pix_stride, int32_t out_pix_stride, int32_t fmt, void* stream);
+/* dx of miseg_maxpool2x2_fwd: the gradient goes to the first maximum of each window in row-major
+ * order.  x: pool input [N,H,W,C], dy: [N,H/2,W/2,C], bf16. */
+int miseg_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+                         int32_t C, int32_t x_pix_stride, int32_t dy_pix_stride,
+                         int32_t dx_pix_stride, void* stream);
+/* 3x3 neighbourhoods of a 3-channel fp32 image as 32 channels per pixel (element (ky*3+kx)*3+c, zero
+ * outside the image and above 26): VGG's block1_conv1 (3 -> 64, 3x3 'same') then runs as a 1x1
+ * convolution.  taps = 9: as described; taps = 1: the centre tap only, i.e. the image zero-padded to 32
+ * channels (the training path's form, whose weight gradient then has the layer's own layout).
+ * in fp32 [N,H,W,3] -> out 16-bit [N,H,W,32] in storage format fmt. */
+int miseg_im2col3x3_fwd(const float* in, void* out, int32_t N, int32_t H, int32_t W, int32_t taps,
+                        int32_t fmt, void* stream);
+/* Backward of a ReLU that follows a convolution directly (Conv2D(activation="relu"), the VGG layers):
+ * dx = (y > 0 ? dy : 0) + addend (addend may be NULL); y is the ReLU's output.  bf16. */
+int miseg_relu_bwd(const void* y, const void* dy, const void* addend, void* dx, int64_t pixels, int32_t C,
+                   int32_t y_pix_stride, int32_t dy_pix_stride, int32_t addend_pix_stride,
+                   int32_t dx_pix_stride, void* stream);
 /* dx[n,y,x,c] = dy[n,y/2,x/2,c] / 4.  H, W are the pool INPUT dims. */
 int miseg_avgpool2x2_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                          int32_t dy_pix_stride, int32_t dx_pix_stride, void* stream);
@@ -576,6 +598,10 @@ int miseg_plan_add_maxpool3x3s2(miseg_plan* p, const void* in, void* out, const 
 int miseg_plan_add_avgpool2x2(miseg_plan* p, const void* in, void* out, int32_t N, int32_t H,
                               int32_t W, int32_t C, int32_t in_pix_stride,
                               int32_t out_pix_stride);
+int miseg_plan_add_maxpool2x2(miseg_plan* p, const void* in, void* out, int32_t N, int32_t H,
+                              int32_t W, int32_t C, int32_t in_pix_stride,
+                              int32_t out_pix_stride);
+int miseg_plan_add_im2col3x3(miseg_plan* p, const float* in, void* out, int32_t N, int32_t H, int32_t W);
 int miseg_plan_add_upsample_nearest(miseg_plan* p, const void* in, const void* addend, void* out,
                                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t shift,
                                     int32_t in_pix_stride, int32_t add_pix_stride,

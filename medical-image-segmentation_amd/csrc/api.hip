@@ -48,6 +48,9 @@ int launch_augment(const float*, const float*, float*, float*, int, int, int, in
 int launch_maxpool3x3s2_bwd(const void*, const void*, void*, int, int, int, int, int, int, int,
                             hipStream_t);
 int launch_avgpool2x2_bwd(const void*, void*, int, int, int, int, int, int, hipStream_t);
+int launch_maxpool2x2_bwd(const void*, const void*, void*, int, int, int, int, int, int, int, hipStream_t);
+int launch_relu_bwd(const void*, const void*, const void*, void*, long long, int, int, int, int, int,
+                    hipStream_t);
 int launch_upsample_nearest_bwd(const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 int launch_upsample_bilinear2x_bwd(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int launch_copy_channels(const void*, const void*, void*, long long, int, int, int, int, hipStream_t);
@@ -65,7 +68,8 @@ namespace miseg_f16 {
 }
 namespace miseg {
 
-enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD, OP_DENSE, OP_LTAIL, OP_FPNHEAD };
+enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD, OP_DENSE, OP_LTAIL, OP_FPNHEAD,
+              OP_MAXPOOL2, OP_IM2COL };
 
 struct Op {
   OpKind kind;
@@ -94,6 +98,8 @@ static int run_op_f16(const Op& o, hipStream_t s) {
     case OP_MAXPOOL:
       return F::launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
     case OP_AVGPOOL: return F::launch_avgpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_MAXPOOL2: return F::launch_maxpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_IM2COL: return F::launch_im2col3x3((const float*)o.in, o.out, o.N, o.H, o.W, 9, s);
     case OP_UPNEAR:
       return F::launch_upsample_nearest(o.in, o.in2, o.out, o.N, o.H, o.W, o.C, o.shift_bits, o.ips,
                                         o.aps, o.ops, s);
@@ -117,6 +123,8 @@ static int run_op(const Op& o, hipStream_t s, int fmt) {
     case OP_MAXPOOL:
       return launch_maxpool3x3s2(o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
     case OP_AVGPOOL: return launch_avgpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_MAXPOOL2: return launch_maxpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
+    case OP_IM2COL: return launch_im2col3x3((const float*)o.in, o.out, o.N, o.H, o.W, 9, s);
     case OP_UPNEAR:
       return launch_upsample_nearest(o.in, o.in2, o.out, o.N, o.H, o.W, o.C, o.shift_bits, o.ips,
                                      o.aps, o.ops, s);
@@ -357,6 +365,26 @@ int miseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, i
                            int32_t C, int32_t xps, int32_t dps, int32_t ops, void* stream) {
   return launch_maxpool3x3s2_bwd(x, dy, dx, N, H, W, C, xps, dps, ops, (hipStream_t)stream);
 }
+int miseg_maxpool2x2_fwd(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t ips, int32_t ops, int32_t fmt, void* stream) {
+  MISEG_CHECK_FMT(fmt);
+  if (fmt == MISEG_FMT_F16) return miseg_f16::launch_maxpool2x2(in, out, N, H, W, C, ips, ops, (hipStream_t)stream);
+  return launch_maxpool2x2(in, out, N, H, W, C, ips, ops, (hipStream_t)stream);
+}
+int miseg_im2col3x3_fwd(const float* in, void* out, int32_t N, int32_t H, int32_t W, int32_t taps,
+                        int32_t fmt, void* stream) {
+  MISEG_CHECK_FMT(fmt);
+  if (fmt == MISEG_FMT_F16) return miseg_f16::launch_im2col3x3(in, out, N, H, W, taps, (hipStream_t)stream);
+  return launch_im2col3x3(in, out, N, H, W, taps, (hipStream_t)stream);
+}
+int miseg_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
+                         int32_t C, int32_t xps, int32_t dps, int32_t ops, void* stream) {
+  return launch_maxpool2x2_bwd(x, dy, dx, N, H, W, C, xps, dps, ops, (hipStream_t)stream);
+}
+int miseg_relu_bwd(const void* y, const void* dy, const void* addend, void* dx, int64_t pixels, int32_t C,
+                   int32_t yps, int32_t dps, int32_t aps, int32_t ops, void* stream) {
+  return launch_relu_bwd(y, dy, addend, dx, pixels, C, yps, dps, aps, ops, (hipStream_t)stream);
+}
 int miseg_avgpool2x2_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
                          int32_t dps, int32_t ops, void* stream) {
   return launch_avgpool2x2_bwd(dy, dx, N, H, W, C, dps, ops, (hipStream_t)stream);
@@ -506,6 +534,25 @@ int miseg_plan_add_avgpool2x2(miseg_plan* p, const void* in, void* out, int32_t 
   return MISEG_OK;
 }
 
+int miseg_plan_add_maxpool2x2(miseg_plan* p, const void* in, void* out, int32_t N, int32_t H,
+                              int32_t W, int32_t C, int32_t ips, int32_t ops) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  Op o{};
+  o.kind = OP_MAXPOOL2; o.in = in; o.out = out;
+  o.N = N; o.H = H; o.W = W; o.C = C; o.ips = ips; o.ops = ops;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
+int miseg_plan_add_im2col3x3(miseg_plan* p, const float* in, void* out, int32_t N, int32_t H, int32_t W) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  Op o{};
+  o.kind = OP_IM2COL; o.in = in; o.out = out;
+  o.N = N; o.H = H; o.W = W;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
 int miseg_plan_add_upsample_nearest(miseg_plan* p, const void* in, const void* addend, void* out,
                                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t shift,
                                     int32_t ips, int32_t aps, int32_t ops) {
@@ -594,7 +641,8 @@ int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t bufl
   const Op& o = p->ops[index];
   static const char* names[] = {"", "prep_input_kernel", "maxpool3x3s2_kernel", "avgpool2x2_kernel",
                                 "upsample_nearest_kernel", "upsample_bilinear2x_kernel",
-                                "scale_shift_relu_kernel"};
+                                "scale_shift_relu_kernel", "", "", "", "", "maxpool2x2_kernel",
+                                "im2col3x3_kernel"};
   if (o.kind == OP_CONV)
     conv_kernel_name(&o.conv, buf, buflen);
   else if (o.kind == OP_CONV_HEAD)

@@ -208,6 +208,92 @@ int launch_avgpool2x2(const void* in, void* out, int N, int H, int W, int C, int
 }
 
 // ---------------------------------------------------------------------------------
+// max pool 2x2 stride 2 (keras_applications VGG block pools)
+// ---------------------------------------------------------------------------------
+__global__ void maxpool2x2_kernel(const h16_t* __restrict__ in, h16_t* __restrict__ out, int N,
+                                  int H, int W, int C, int ips, int ops) {
+  const int Ho = H >> 1, Wo = W >> 1, C8 = C >> 3;
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float best[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) best[j] = -3.0e38f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        float t[8];
+        unpack8(t, *reinterpret_cast<const uint4*>(
+                       in + (((long long)n * H + 2 * oy + dy) * W + 2 * ox + dx) * ips + c8 * 8));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], t[j]);
+      }
+    *reinterpret_cast<uint4*>(out + (((long long)n * Ho + oy) * Wo + ox) * ops + c8 * 8) =
+        pack8(best);      // exact: the maximum is one of the stored values
+  }
+}
+
+int launch_maxpool2x2(const void* in, void* out, int N, int H, int W, int C, int ips, int ops,
+                      hipStream_t s) {
+  MISEG_CHECK_ARG(in && out, "maxpool2x2: null pointer");
+  MISEG_CHECK_ARG(N > 0 && H > 1 && W > 1 && (H & 1) == 0 && (W & 1) == 0 && C > 0 && (C & 7) == 0 &&
+                      (ips & 7) == 0 && (ops & 7) == 0 && ips >= C && ops >= C,
+                  "maxpool2x2: H and W must be even, C and strides multiples of 8");
+  const long long total = (long long)N * (H >> 1) * (W >> 1) * (C >> 3);
+  hipLaunchKernelGGL(maxpool2x2_kernel, dim3(grid_for(total)), dim3(256), 0, s, (const h16_t*)in,
+                     (h16_t*)out, N, H, W, C, ips, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// fp32 [N][H][W][3] -> 16-bit [N][H][W][32]: the 3x3 neighbourhood of every pixel (zero outside the
+// image), element (ky*3 + kx)*3 + c = in[y + ky - 1][x + kx - 1][c], elements 27..31 zero.  A 3x3
+// 'same' convolution of the 3-channel image is then a 1x1 convolution with 32 input channels.
+// taps == 1: the centre tap only, i.e. the image itself padded to 32 channels.
+// ---------------------------------------------------------------------------------
+__global__ void im2col3x3_kernel(const float* __restrict__ in, h16_t* __restrict__ out, int N, int H,
+                                 int W, int taps) {
+  const long long total = (long long)N * H * W * 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 3);
+    long long r = i >> 2;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = q * 8 + j;
+      const int t = k / 3, c = k - t * 3;
+      const int tap = taps == 9 ? t : 4;
+      const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+      v[j] = (k < 3 * taps && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                 ? in[(((long long)n * H + yy) * W + xx) * 3 + c]
+                 : 0.f;
+    }
+    *reinterpret_cast<uint4*>(out + i * 8) = pack8(v);
+  }
+}
+
+int launch_im2col3x3(const float* in, void* out, int N, int H, int W, int taps, hipStream_t s) {
+  MISEG_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && (taps == 9 || taps == 1), "im2col3x3: bad argument");
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for((long long)N * H * W * 4)), dim3(256), 0, s, in,
+                     (h16_t*)out, N, H, W, taps);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // nearest upsample by 2^shift, optional add
 // ---------------------------------------------------------------------------------
 __global__ void upsample_nearest_kernel(const h16_t* __restrict__ in,

@@ -519,6 +519,96 @@ int launch_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int 
   return MISEG_OK;
 }
 
+// ------------------------------------------------------------------ max pool 2x2 backward
+// One thread per output window and 8 channels: the gradient goes to the first maximum of the window in
+// row-major order, the other three inputs get zero.
+__global__ void maxpool2x2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                      bf16_t* __restrict__ dx, int N, int H, int W, int C, int xps,
+                                      int dps, int ops) {
+  const int Ho = H >> 1, Wo = W >> 1, C8 = C >> 3;
+  const long long total = (long long)N * Ho * Wo * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % C8);
+    long long r = i / C8;
+    const int ox = (int)(r % Wo);
+    r /= Wo;
+    const int oy = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float g[8], best[8];
+    int bidx[8];
+    unpack8f(g, *reinterpret_cast<const uint4*>(dy + (((long long)n * Ho + oy) * Wo + ox) * dps + c8 * 8));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -3.0e38f; bidx[j] = -1; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[8];
+      unpack8f(v, *reinterpret_cast<const uint4*>(
+                      x + (((long long)n * H + 2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * xps + c8 * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (v[j] > best[j]) { best[j] = v[j]; bidx[j] = q; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = bidx[j] == q ? g[j] : 0.f;
+      *reinterpret_cast<uint4*>(dx + (((long long)n * H + 2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * ops +
+                                c8 * 8) = pack8f(o);
+    }
+  }
+}
+
+int launch_maxpool2x2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int xps,
+                          int dps, int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(x && dy && dx && N > 0 && H > 1 && W > 1 && (H & 1) == 0 && (W & 1) == 0 && C > 0 &&
+                      (C & 7) == 0 && (xps & 7) == 0 && (dps & 7) == 0 && (ops & 7) == 0,
+                  "maxpool2x2_bwd: H and W must be even, C and strides multiples of 8");
+  const long long total = (long long)N * (H >> 1) * (W >> 1) * (C >> 3);
+  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(grid_cap(total, 256, 8192)), dim3(256), 0, s,
+                     (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, xps, dps, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// ------------------------------------------------------------------ ReLU backward (no BatchNorm in between)
+// dx = (y > 0 ? dy : 0) [+ addend]; y is the ReLU's output.
+__global__ void relu_bwd_kernel(const bf16_t* __restrict__ y, const bf16_t* __restrict__ dy,
+                                const bf16_t* __restrict__ add, bf16_t* __restrict__ dx, long long pixels,
+                                int C, int yps, int dps, int aps, int ops) {
+  const int C8 = C >> 3;
+  ChanWalk w(pixels, C8);
+  if (!w.active) return;
+  const int c8 = w.c8;
+  for (long long pix = w.pix0; pix < pixels; pix += w.pstep) {
+    float a[8], g[8];
+    unpack8f(a, *reinterpret_cast<const uint4*>(y + pix * yps + c8 * 8));
+    unpack8f(g, *reinterpret_cast<const uint4*>(dy + pix * dps + c8 * 8));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = a[j] > 0.f ? g[j] : 0.f;
+    if (add) {
+      float b[8];
+      unpack8f(b, *reinterpret_cast<const uint4*>(add + pix * aps + c8 * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] += b[j];
+    }
+    *reinterpret_cast<uint4*>(dx + pix * ops + c8 * 8) = pack8f(g);
+  }
+}
+
+int launch_relu_bwd(const void* y, const void* dy, const void* add, void* dx, long long pixels, int C,
+                    int yps, int dps, int aps, int ops, hipStream_t s) {
+  MISEG_CHECK_ARG(y && dy && dx && pixels > 0 && C > 0 && (C & 7) == 0 && (yps & 7) == 0 &&
+                      (dps & 7) == 0 && (ops & 7) == 0 && (!add || (aps & 7) == 0),
+                  "relu_bwd: bad argument");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_cap(pixels * (C >> 3), 256, 8192)), dim3(256), 0, s,
+                     (const bf16_t*)y, (const bf16_t*)dy, (const bf16_t*)add, (bf16_t*)dx, pixels, C, yps,
+                     dps, aps, ops);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
 __global__ void avgpool2x2_bwd_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int N,
                                       int H, int W, int C, int dps, int ops) {
   const int Ho = H >> 1, Wo = W >> 1, C8 = C >> 3;

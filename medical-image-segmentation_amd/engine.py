@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import lib as L
-from .netspec import RESNET_UNITS, RESNET_BOTTLENECK, DENSENET_LAYERS
+from .netspec import RESNET_UNITS, RESNET_BOTTLENECK, DENSENET_LAYERS, VGG_BLOCKS
 
 
 class View:
@@ -428,6 +428,36 @@ class Engine:
         self.taps["relu"] = out
         return out
 
+    def _vgg(self, blocks, skip_dst):
+        """keras_applications VGG-16/19: 3x3 convolutions with bias and ReLU (the epilogue's shift and
+        activation), MaxPooling2D(2) after each block.  block1_conv1 reads the fp32 image through its
+        3x3 neighbourhoods laid out as 32 channels, i.e. as a 1x1 convolution."""
+        col = self.buf(self.h, self.wd, 32)
+        self._add(self.lib.miseg_plan_add_im2col3x3(self.plan, self.x_in.data_ptr(), col.ptr, self.n,
+                                                    self.h, self.wd), "im2col3x3")
+        x = col
+        for b, reps in enumerate(blocks):
+            for i in range(reps):
+                name = "block%d_conv%d" % (b + 1, i + 1)
+                k = self.w[name]["kernel"]
+                cout = k.shape[3]
+                out = (skip_dst.get(name) if i + 1 == reps else None) or self.buf(x.h, x.w, cout)
+                if x is col:
+                    w1 = np.zeros((cout, 1, 1, 32), np.float32)
+                    w1[:, 0, 0, :27] = k.transpose(3, 0, 1, 2).reshape(cout, 27)
+                    self.conv(name, x, self.dev_h16(w1), cout, 1, out=out, shift=self.w[name]["bias"],
+                              act=L.ACT_RELU)
+                else:
+                    self.conv(name, x, self.conv_weight(name), cout, 3, pad=1, out=out,
+                              shift=self.w[name]["bias"], act=L.ACT_RELU)
+                self.taps[name] = out
+                x = out
+            pooled = self.buf(x.h // 2, x.w // 2, x.c)
+            self._add(self.lib.miseg_plan_add_maxpool2x2(self.plan, x.ptr, pooled.ptr, self.n, x.h, x.w,
+                                                         x.c, x.pix, pooled.pix), "block%d_pool" % (b + 1))
+            x = pooled
+        return x
+
     # -------------------------------------------------------------- decoders
     def _head(self, name, x, build_only=False):
         act = L.ACT_SIGMOID if self.g.activation == "sigmoid" else L.ACT_SOFTMAX
@@ -526,22 +556,28 @@ class Engine:
             h, w = enc_out.h, enc_out.w
             for i, f in enumerate((512, 256, 128, 64, 32)):
                 h, w = 2 * h, 2 * w
-                sc = skip_syms[i].c if i < 4 else 0
+                sc = skip_syms[i].c if i < len(skip_syms) else 0
                 cb = self.buf(h, w, _ceil32(f + sc))
                 concat.append(cb)
-                if i < 4:
+                if sc:
                     skip_dst[skip_names[i]] = cb.slice(f, sc)
         if enc in RESNET_UNITS:
             x = self._resnet(RESNET_UNITS[enc], skip_dst, enc in RESNET_BOTTLENECK)
+        elif enc in VGG_BLOCKS:
+            x = self._vgg(VGG_BLOCKS[enc], skip_dst)
         else:
             x = self._densenet(DENSENET_LAYERS[enc], skip_dst)
         skips = [self.taps[n] for n in skip_names]
+        if dec != "FPN" and "center_block1_conv" in self.w:
+            # the backbone ends in a pooling layer (the VGGs): two Conv3x3BnReLU(512) blocks first
+            x = self.conv_bn_relu("center_block1", x, 3)
+            x = self.conv_bn_relu("center_block2", x, 3)
         if dec == "U-Net":
             for i, f in enumerate((512, 256, 128, 64, 32)):
                 cb = concat[i]
                 self.convT_bn_relu("decoder_stage%da_transpose" % i, "decoder_stage%da_bn" % i, x,
                                    out=cb.slice(0, f))
-                xin = cb.slice(0, f + (skips[i].c if i < 4 else 0))
+                xin = cb.slice(0, f + (skips[i].c if i < len(skips) else 0))
                 if i == 4 and self.fuse_tail and _ceil32(xin.c) == 32 and self.classes <= 4 and \
                         self.w["decoder_stage4b_conv"]["kernel"].shape[3] == 32:
                     self._unet_tail("decoder_stage4b", xin, "final_conv")
@@ -565,7 +601,8 @@ class Engine:
                 # Add([relu(bn(conv)), skip]): the skip is added after the activation, in the
                 # convolution's epilogue
                 self.conv(base, x, self.conv_weight(base + "_conv"), cout, 1, out=out, scale=s,
-                          shift=t, act=L.ACT_RELU, residual=skips[i] if i < 4 else None, res_after=i < 4)
+                          shift=t, act=L.ACT_RELU, residual=skips[i] if i < len(skips) else None,
+                          res_after=i < len(skips))
                 self.taps["decoder_stage%d_out" % i] = out
                 x = out
             if x is not None:

@@ -51,11 +51,15 @@ def infer_architecture(config):
     elif "conv2_block1_0_bn" in nameset:
         blocks = tuple(count("conv%d_block%%d_0_bn" % s) for s in (2, 3, 4, 5))
         enc = {v: k for k, v in netspec.DENSENET_LAYERS.items()}.get(blocks)
+    elif "block1_conv1" in nameset and "block5_pool" in nameset:
+        blocks = tuple(count("block%d_conv%%d" % s) for s in (1, 2, 3, 4, 5))
+        enc = {v: k for k, v in netspec.VGG_BLOCKS.items()}.get(blocks)
     else:
         enc = None
     if enc is None:
         raise ValueError("the encoder of this model is not one of %s"
-                         % sorted(list(netspec.RESNET_UNITS) + list(netspec.DENSENET_LAYERS)))
+                         % sorted(list(netspec.RESNET_UNITS) + list(netspec.DENSENET_LAYERS) +
+                                  list(netspec.VGG_BLOCKS)))
     if "decoder_stage0a_transpose" in nameset:
         dec, head = "U-Net", "final_conv"
     elif "decoder_stage0b_transpose" in nameset:
@@ -144,8 +148,8 @@ def _keras_layer_config(l):
         c["strides"] = [c["strides"]] * 2
         c["kernel_initializer"] = {"class_name": "HeUniform" if c.get("kernel_initializer") == "he_uniform"
                                    else "GlorotUniform", "config": {"seed": None}}
-        c.update({"dilation_rate": [1, 1], "groups": 1, "activation": "linear", "data_format": "channels_last",
-                  "trainable": True, "dtype": "float32"})
+        c.update({"dilation_rate": [1, 1], "groups": 1, "activation": c.get("activation", "linear"),
+                  "data_format": "channels_last", "trainable": True, "dtype": "float32"})
     elif l.cls == "ZeroPadding2D":
         p = c["padding"]
         c["padding"] = [[p, p], [p, p]]

@@ -129,6 +129,10 @@ SIGNATURES = {
                                           _FP, C.c_float, _I32, _VP, _VP, _I32, _VP]),
     "miseg_maxpool3x3s2_bwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_avgpool2x2_bwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_maxpool2x2_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_maxpool2x2_bwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_im2col3x3_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_relu_bwd": (C.c_int, [_VP, _VP, _VP, _VP, _I64, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_upsample_nearest_bwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_upsample_bilinear2x_bwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_copy_channels": (C.c_int, [_VP, _VP, _VP, _I64, _I32, _I32, _I32, _I32, _VP]),
@@ -162,6 +166,8 @@ SIGNATURES = {
     "miseg_plan_add_prep_input": (C.c_int, [_VP, _FP, _VP, _FP, _FP, _I32, _I32, _I32]),
     "miseg_plan_add_maxpool3x3s2": (C.c_int, [_VP, _VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32]),
     "miseg_plan_add_avgpool2x2": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "miseg_plan_add_maxpool2x2": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "miseg_plan_add_im2col3x3": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32]),
     "miseg_plan_add_upsample_nearest": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "miseg_plan_add_upsample_bilinear2x": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
     "miseg_plan_add_scale_shift_relu": (C.c_int, [_VP, _VP, _VP, _FP, _FP, _I64, _I32, _I32, _I32]),

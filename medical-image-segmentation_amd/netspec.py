@@ -1,6 +1,6 @@
 """Symbolic layer graphs of the networks `make_model` builds
 (/root/reference utils/model.py:175-211): encoders ResNet-18/34/50/101/152
-(classification_models) and DenseNet-121/169/201 (keras_applications), decoders
+(classification_models), DenseNet-121/169/201 and VGG-16/19 (keras_applications), decoders
 U-Net, Linknet and FPN (segmentation_models) with the hyper-parameters the
 reference fixes.  A graph is an ordered list of Keras-style layer records
 (name, class, config, inbound layers, weights); it carries the layer and weight
@@ -16,6 +16,8 @@ BACKBONE_FEATURES = {
     "resnet50": ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0"),
     "resnet101": ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0"),
     "resnet152": ("stage4_unit1_relu1", "stage3_unit1_relu1", "stage2_unit1_relu1", "relu0"),
+    "vgg16": ("block5_conv3", "block4_conv3", "block3_conv3", "block2_conv2", "block1_conv2"),
+    "vgg19": ("block5_conv4", "block4_conv4", "block3_conv4", "block2_conv2", "block1_conv2"),
     "densenet121": (311, 139, 51, 4),
     "densenet169": (367, 139, 51, 4),
     "densenet201": (479, 139, 51, 4),
@@ -25,6 +27,7 @@ RESNET_UNITS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": 
 # classification_models residual_bottleneck_block (1x1, 3x3, 1x1 to four times the filters) instead of
 # residual_conv_block (3x3, 3x3)
 RESNET_BOTTLENECK = ("resnet50", "resnet101", "resnet152")
+VGG_BLOCKS = {"vgg16": (2, 2, 3, 3, 3), "vgg19": (2, 2, 4, 4, 4)}      # keras_applications vgg16.py / vgg19.py
 DENSENET_LAYERS = {"densenet121": (6, 12, 24, 16), "densenet169": (6, 12, 32, 32),
                    "densenet201": (6, 12, 48, 32)}
 
@@ -88,7 +91,7 @@ class Graph:
                          x.h + 2 * p, x.w + 2 * p, x.c)
 
     def conv(self, x, filters, k, name, strides=1, padding="valid", use_bias=False,
-             init="glorot_uniform"):
+             init="glorot_uniform", activation="linear"):
         if padding == "same":
             h, w = -(-x.h // strides), -(-x.w // strides)
         else:
@@ -97,7 +100,7 @@ class Graph:
         if use_bias:
             ws.append(("bias", (filters,), "zeros"))
         cfg = {"filters": filters, "kernel_size": k, "strides": strides, "padding": padding,
-               "use_bias": use_bias, "kernel_initializer": init}
+               "use_bias": use_bias, "kernel_initializer": init, "activation": activation}
         return self._add(name, "Conv2D", cfg, [x], ws, h, w, filters)
 
     def conv_transpose(self, x, filters, name):
@@ -120,9 +123,9 @@ class Graph:
         return self._add(name, "TemperatureScaledSoftmax", {"temperature": temperature}, [x], [],
                          x.h, x.w, x.c)
 
-    def maxpool(self, x, name):
-        return self._add(name, "MaxPooling2D", {"pool_size": 3, "strides": 2, "padding": "valid"},
-                         [x], [], (x.h - 3) // 2 + 1, (x.w - 3) // 2 + 1, x.c)
+    def maxpool(self, x, name, pool=3):
+        return self._add(name, "MaxPooling2D", {"pool_size": pool, "strides": 2, "padding": "valid"},
+                         [x], [], (x.h - pool) // 2 + 1, (x.w - pool) // 2 + 1, x.c)
 
     def avgpool(self, x, name):
         return self._add(name, "AveragePooling2D", {"pool_size": 2, "strides": 2}, [x], [],
@@ -199,6 +202,15 @@ def _resnet(g, x, units, bottleneck=False):
     return g.act(x, "relu", "relu1")
 
 
+def _vgg(g, x, blocks):
+    for b, (reps, filters) in enumerate(zip(blocks, (64, 128, 256, 512, 512))):
+        for i in range(reps):
+            x = g.conv(x, filters, 3, "block%d_conv%d" % (b + 1, i + 1), padding="same", use_bias=True,
+                       activation="relu")
+        x = g.maxpool(x, "block%d_pool" % (b + 1), pool=2)
+    return x
+
+
 def _densenet(g, x, block_layers):
     eps = 1.001e-5
     x = g.zero_pad(x, 3)
@@ -240,7 +252,17 @@ def _conv_bn_relu(g, x, filters, k, name):
     return g.act(x, "relu", name + "_relu")
 
 
+def _center(g, x):
+    """segmentation_models build_unet / build_linknet: a backbone ending in MaxPooling2D (the VGGs)
+    gets two Conv3x3BnReLU(512) blocks in front of the decoder."""
+    if g.layers[x.layer].cls == "MaxPooling2D":
+        x = _conv_bn_relu(g, x, 512, 3, "center_block1")
+        x = _conv_bn_relu(g, x, 512, 3, "center_block2")
+    return x
+
+
 def _unet(g, x, skips, classes):
+    x = _center(g, x)
     for i, f in enumerate((512, 256, 128, 64, 32)):
         x = g.conv_transpose(x, f, "decoder_stage%da_transpose" % i)
         x = g.bn(x, "decoder_stage%da_bn" % i, DEC_EPS)
@@ -252,6 +274,7 @@ def _unet(g, x, skips, classes):
 
 
 def _linknet(g, x, skips, classes):
+    x = _center(g, x)
     for i in range(5):
         cin = x.c
         cout = skips[i].c if i < len(skips) else 16
@@ -306,11 +329,13 @@ def build_graph(encoder, decoder, input_shape, classes, activation=None, tempera
     x = g.input(h, w, c, "data" if encoder in RESNET_UNITS else "input_1")
     if encoder in RESNET_UNITS:
         x = _resnet(g, x, RESNET_UNITS[encoder], encoder in RESNET_BOTTLENECK)
+    elif encoder in VGG_BLOCKS:
+        x = _vgg(g, x, VGG_BLOCKS[encoder])
     elif encoder in DENSENET_LAYERS:
         x = _densenet(g, x, DENSENET_LAYERS[encoder])
     else:
         raise ValueError("unsupported encoder %r (supported: %s)" %
-                         (encoder, sorted(list(RESNET_UNITS) + list(DENSENET_LAYERS))))
+                         (encoder, sorted(list(RESNET_UNITS) + list(DENSENET_LAYERS) + list(VGG_BLOCKS))))
     skips = [g.sym(k) for k in BACKBONE_FEATURES[encoder]]
     g.skip_layers = [s.layer for s in skips]
     g.encoder_output = x.layer

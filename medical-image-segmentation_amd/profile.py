@@ -43,6 +43,7 @@ class TimedLib:
         self._lib = lib
         self.on = False
         self.records = []
+        self.tag = ""                  # set by the caller: which layer the next calls belong to
         self._note = None
 
     def note(self, kernel, macs=0, nbytes=0):
@@ -68,7 +69,7 @@ class TimedLib:
             if note is None:
                 f = BYTES.get(name)
                 note = (name.replace("miseg_", "") + "_kernel", 0, f([a or 0 for a in args]) if f else 0)
-            self.records.append((name, note, e0, e1))
+            self.records.append((name, note, e0, e1, self.tag))
             return rc
         return call
 
@@ -76,10 +77,16 @@ class TimedLib:
         """{kernel: {"launches", "ms", "flops", "bytes"}} of the recorded calls (synchronises)."""
         torch.cuda.synchronize()
         out = collections.OrderedDict()
-        for name, (kernel, macs, nbytes), e0, e1 in self.records:
+        for name, (kernel, macs, nbytes), e0, e1, _ in self.records:
             g = out.setdefault(kernel, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "entry": name})
             g["launches"] += 1
             g["ms"] += e0.elapsed_time(e1)
             g["flops"] += 2.0 * macs
             g["bytes"] += float(nbytes)
         return out
+
+    def calls(self):
+        """[(layer tag, kernel, ms, flops, bytes)] of the recorded calls in launch order (synchronises)."""
+        torch.cuda.synchronize()
+        return [(tag, kernel, e0.elapsed_time(e1), 2.0 * macs, float(nbytes))
+                for _, (kernel, macs, nbytes), e0, e1, tag in self.records]

@@ -513,6 +513,7 @@ class Trainer:
         for name in self.order:
             l = g.layers[name]
             cls = l.cls
+            lib.tag = "fwd " + name
             if cls in ("InputLayer", "ZeroPadding2D"):
                 continue
             if cls == "BatchNormalization" and g.layers[l.inbound[0]].cls == "InputLayer":
@@ -539,7 +540,15 @@ class Trainer:
                 if k == 7:
                     self._stem_forward(l, src)
                     continue
+                if g.layers[src].cls == "InputLayer" and src not in self.acts:
+                    # a 3x3 convolution on the image itself (VGG block1_conv1): the fp32 image as a
+                    # bf16 tensor zero-padded to 32 channels
+                    t = torch.empty((n, self.H, self.W, 32), dtype=torch.bfloat16, device=self.dev)
+                    L.check(lib.miseg_im2col3x3_fwd(self.x_in.data_ptr(), t.data_ptr(), n, self.H, self.W, 1,
+                                                    L.FMT_BF16, st))
+                    self.acts[src] = Act(t, 3)
                 xin = self.acts[src]
+                relu = l.config.get("activation") == "relu"
                 if name == g.logits_layer:
                     probs = torch.empty((n, l.out.h, l.out.w, co), dtype=torch.float32, device=self.dev)
                     act = L.ACT_SIGMOID if g.activation == "sigmoid" else L.ACT_SOFTMAX
@@ -551,7 +560,8 @@ class Trainer:
                     continue
                 out = self.new_out(name, l.out.h, l.out.w, co)
                 self.conv(xin, self.wptr(name), co, k, k, stride, stride, pad, pad, out, l.out.h, l.out.w,
-                          bias=bias, stats=self._stats_for(name, co))
+                          bias=bias, stats=None if relu else self._stats_for(name, co),
+                          act=L.ACT_RELU if relu else L.ACT_NONE)
                 self.acts[name] = out
                 self.saved[name] = (xin, pad)
             elif cls == "Conv2DTranspose":
@@ -601,8 +611,12 @@ class Trainer:
                 src, _ = self._src(l.inbound[0])
                 xin = self.acts[src]
                 out = self.new_out(name, l.out.h, l.out.w, l.out.c)
-                L.check(lib.miseg_maxpool3x3s2_fwd(xin.ptr, out.ptr, None, None, n, xin.h, xin.w, xin.c,
-                                                   xin.pix, out.pix, st))
+                if l.config["pool_size"] == 2:
+                    L.check(lib.miseg_maxpool2x2_fwd(xin.ptr, out.ptr, n, xin.h, xin.w, xin.c, xin.pix,
+                                                     out.pix, L.FMT_BF16, st))
+                else:
+                    L.check(lib.miseg_maxpool3x3s2_fwd(xin.ptr, out.ptr, None, None, n, xin.h, xin.w, xin.c,
+                                                       xin.pix, out.pix, st))
                 self.acts[name] = out
                 self.saved[name] = xin
             elif cls == "AveragePooling2D":
@@ -748,6 +762,7 @@ class Trainer:
         for name in reversed(self.order):
             l = g.layers[name]
             cls = l.cls
+            lib.tag = "bwd " + name
             if cls in ("InputLayer", "ZeroPadding2D", "TemperatureScaledSoftmax"):
                 continue
             if cls == "Activation":
@@ -768,6 +783,13 @@ class Trainer:
             if self.grad_log is not None:
                 self.accum_final[name] = dy
             if cls == "Conv2D":
+                if l.config.get("activation") == "relu":
+                    # Conv2D(activation="relu"): the gradient of the pre-activation
+                    y = self.acts[name]
+                    pre = self.new(y.h, y.w, y.c)
+                    L.check(lib.miseg_relu_bwd(y.ptr, dy.ptr, None, pre.ptr, y.pixels, y.c, y.pix, dy.pix, 0,
+                                               pre.pix, st))
+                    dy = pre
                 self._conv_backward(l, dy, grads)
             elif cls == "Conv2DTranspose":
                 self._convT_backward(l, dy, grads)
@@ -795,8 +817,12 @@ class Trainer:
             elif cls == "MaxPooling2D":
                 xin = self.saved[name]
                 dx = self.new(xin.h, xin.w, xin.c)
-                L.check(lib.miseg_maxpool3x3s2_bwd(xin.ptr, dy.ptr, dx.ptr, n, xin.h, xin.w, xin.c, xin.pix,
-                                                   dy.pix, dx.pix, st))
+                if l.config["pool_size"] == 2:
+                    L.check(lib.miseg_maxpool2x2_bwd(xin.ptr, dy.ptr, dx.ptr, n, xin.h, xin.w, xin.c, xin.pix,
+                                                     dy.pix, dx.pix, st))
+                else:
+                    L.check(lib.miseg_maxpool3x3s2_bwd(xin.ptr, dy.ptr, dx.ptr, n, xin.h, xin.w, xin.c, xin.pix,
+                                                       dy.pix, dx.pix, st))
                 self._accum(grads, self._src(l.inbound[0])[0], dx, name, dy)
             elif cls == "AveragePooling2D":
                 src = g.layers[l.inbound[0]].out

@@ -1,7 +1,8 @@
 """Functional restatement of the network graphs that the reference builds at
 utils/model.py:175-211 through segmentation_models 1.0.1 (`sm.Unet`,
 `sm.Linknet`, `sm.FPN`) on the encoders of image-classifiers 1.0.0
-(ResNet-18/34) and keras-applications 1.0.8 (DenseNet-169).  TEST
+(ResNet-18/34/50/101/152) and keras-applications 1.0.8 (DenseNet-121/169/201,
+VGG-16/19).  TEST
 INFRASTRUCTURE: see oracle/__init__.py.
 
 The graph code is written once against an op back-end (`oracle.ops_np` or
@@ -21,6 +22,10 @@ RESNET_REPS = {"resnet18": (2, 2, 2, 2), "resnet34": (3, 4, 6, 3), "resnet50": (
 RESNET_BOTTLENECK = ("resnet50", "resnet101", "resnet152")      # [UPSTREAM] residual_bottleneck_block
 DENSENET_BLOCKS = {"densenet169": (6, 12, 32, 32), "densenet121": (6, 12, 24, 16),
                    "densenet201": (6, 12, 48, 32)}
+# keras-applications 1.0.8 vgg16.py / vgg19.py: 3x3 convolutions with bias and ReLU, five blocks of
+# (64, 128, 256, 512, 512) filters, each closed by MaxPooling2D(2, strides=2); no batch normalisation
+VGG_BLOCKS = {"vgg16": (2, 2, 3, 3, 3), "vgg19": (2, 2, 4, 4, 4)}
+VGG_FILTERS = (64, 128, 256, 512, 512)
 RESNET_EPS = 2e-5
 DENSENET_EPS = 1.001e-5
 DECODER_EPS = 1e-3
@@ -108,6 +113,16 @@ def _densenet_spec(s, blocks):
     return skip_ch[::-1], c
 
 
+def _vgg_spec(s, blocks):
+    cin = 3
+    for b, (reps, f) in enumerate(zip(blocks, VGG_FILTERS)):
+        for i in range(reps):
+            s.conv("block%d_conv%d" % (b + 1, i + 1), 3, cin, f, bias=True, init="glorot_uniform")
+            cin = f
+    # sm Backbones feature layers: the last convolution of every block, deep -> shallow
+    return list(VGG_FILTERS[::-1]), cin
+
+
 def _conv_bn(s, name, k, cin, cout):
     s.conv(name + "_conv", k, cin, cout)
     s.bn(name + "_bn", cout)
@@ -121,19 +136,27 @@ def build_spec(encoder, decoder, classes):
         skips, c = _resnet_spec(s, RESNET_REPS[encoder], encoder in RESNET_BOTTLENECK)
     elif encoder in DENSENET_BLOCKS:
         skips, c = _densenet_spec(s, DENSENET_BLOCKS[encoder])
+    elif encoder in VGG_BLOCKS:
+        skips, c = _vgg_spec(s, VGG_BLOCKS[encoder])
+        if decoder in ("U-Net", "Linknet"):
+            # [UPSTREAM] build_unet / build_linknet: a backbone that ends in MaxPooling2D gets two
+            # Conv3x3BnReLU(512) "center" blocks in front of the decoder
+            _conv_bn(s, "center_block1", 3, c, 512)
+            _conv_bn(s, "center_block2", 3, 512, 512)
+            c = 512
     else:
         raise ValueError("unsupported encoder %r" % (encoder,))
     if decoder == "U-Net":
         for i, f in enumerate(UNET_FILTERS):
             s.convT("decoder_stage%da_transpose" % i, c, f)
             s.bn("decoder_stage%da_bn" % i, f)
-            cc = f + (skips[i] if i < 4 else 0)
+            cc = f + (skips[i] if i < len(skips) else 0)
             _conv_bn(s, "decoder_stage%db" % i, 3, cc, f)
             c = f
         s.conv("final_conv", 3, c, classes, bias=True, init="glorot_uniform")
     elif decoder == "Linknet":
         for i in range(5):
-            out = skips[i] if i < 4 else LINKNET_LAST_FILTERS
+            out = skips[i] if i < len(skips) else LINKNET_LAST_FILTERS
             _conv_bn(s, "decoder_stage%da" % i, 1, c, c // 4)
             s.convT("decoder_stage%db_transpose" % i, c // 4, c // 4)
             s.bn("decoder_stage%db_bn" % i, c // 4)
@@ -296,12 +319,33 @@ def _densenet_forward(c, x, blocks):
     return x, feats[::-1]
 
 
+def _vgg_forward(c, x, blocks):
+    ops = c.ops
+    feats = []
+    for b, reps in enumerate(blocks):
+        for i in range(reps):
+            name = "block%d_conv%d" % (b + 1, i + 1)
+            x = c.tap(name, ops.relu(c.conv(x, name, pad=1)))
+        feats.append(x)
+        x = ops.maxpool2x2(x)
+    return x, feats[::-1]
+
+
+def _center(c, x):
+    """Two Conv3x3BnReLU(512) blocks when the backbone ends in a pooling layer (the VGGs)."""
+    if "center_block1_conv" in c.w:
+        x = c.conv_bn_relu(x, "center_block1", 3)
+        x = c.conv_bn_relu(x, "center_block2", 3)
+    return x
+
+
 def _unet_decoder(c, x, feats):
     ops = c.ops
+    x = _center(c, x)
     for i in range(5):
         x = c.convT(x, "decoder_stage%da_transpose" % i)
         x = ops.relu(c.bn(x, "decoder_stage%da_bn" % i, DECODER_EPS))
-        if i < 4:
+        if i < len(feats):
             x = ops.concat([x, feats[i]])
         x = c.conv_bn_relu(x, "decoder_stage%db" % i, 3)
     return c.conv(x, "final_conv", pad=1)
@@ -309,12 +353,13 @@ def _unet_decoder(c, x, feats):
 
 def _linknet_decoder(c, x, feats):
     ops = c.ops
+    x = _center(c, x)
     for i in range(5):
         x = c.conv_bn_relu(x, "decoder_stage%da" % i, 1)
         x = c.convT(x, "decoder_stage%db_transpose" % i)
         x = ops.relu(c.bn(x, "decoder_stage%db_bn" % i, DECODER_EPS))
         x = c.conv_bn_relu(x, "decoder_stage%dc" % i, 1)
-        if i < 4:
+        if i < len(feats):
             x = ops.add(x, feats[i])
         c.tap("decoder_stage%d_out" % i, x)
     return c.conv(x, "final_conv", pad=1)
@@ -357,6 +402,8 @@ def forward(ops, encoder, decoder, weights, x, activation="softmax", temperature
     x = ops.asarray(x)
     if encoder in RESNET_REPS:
         x, feats = _resnet_forward(c, x, RESNET_REPS[encoder], encoder in RESNET_BOTTLENECK)
+    elif encoder in VGG_BLOCKS:
+        x, feats = _vgg_forward(c, x, VGG_BLOCKS[encoder])
     else:
         x, feats = _densenet_forward(c, x, DENSENET_BLOCKS[encoder])
     if decoder == "U-Net":

@@ -58,6 +58,10 @@ def maxpool3x3s2_pad1(x):
     return T.maxpool3x3s2_pad1(x)
 
 
+def maxpool2x2(x):
+    return T.maxpool2x2(x)
+
+
 def avgpool2x2(x):
     return r(T.avgpool2x2(x))
 

@@ -105,6 +105,13 @@ def maxpool3x3s2_pad1(x):
     return out
 
 
+def maxpool2x2(x):
+    """MaxPooling2D(2, strides=2), 'valid' (keras_applications VGG block pools)."""
+    n, h, w, c = x.shape
+    h2, w2 = h // 2, w // 2
+    return x[:, :2 * h2, :2 * w2, :].reshape(n, h2, 2, w2, 2, c).max(axis=(2, 4))
+
+
 def avgpool2x2(x):
     """AveragePooling2D(2, strides=2), 'valid'."""
     n, h, w, c = x.shape

@@ -73,6 +73,10 @@ def maxpool3x3s2_pad1(x):
     return _nhwc(F.max_pool2d(F.pad(_nchw(x), (1, 1, 1, 1)), 3, 2))
 
 
+def maxpool2x2(x):
+    return _nhwc(F.max_pool2d(_nchw(x), 2, 2))
+
+
 def avgpool2x2(x):
     return _nhwc(F.avg_pool2d(_nchw(x), 2, 2))
 

@@ -37,6 +37,9 @@ CONFIGS = [
     ("resnet34", "FPN", (64, 96), 2, 4),       # four classes
     ("resnet50", "U-Net", (64, 96), 1, 3),     # bottleneck units (classification_models residual_bottleneck_block)
     ("resnet50", "Linknet", (64, 64), 2, 3),
+    ("vgg16", "U-Net", (64, 96), 1, 3),        # biased convolutions with ReLU, 2x2 max pools, five skips, centre blocks
+    ("vgg16", "Linknet", (64, 64), 2, 3),
+    ("vgg19", "FPN", (64, 64), 1, 1),
 ]
 
 

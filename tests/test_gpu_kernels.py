@@ -577,6 +577,50 @@ def test_pointwise_kernels(env):
     torch.cuda.synchronize()
 
 
+def test_vgg_layer_kernels(env):
+    """The layers only the VGG encoders use: MaxPooling2D(2) and the 3x3 neighbourhood layout of the image
+    that turns block1_conv1 into a 1x1 convolution; both exact."""
+    from oracle import ops_np
+    L, lib, dev = env
+    rng = np.random.default_rng(31)
+    n, h, w, c = 2, 12, 20, 40
+    x = bf16_round(rng.normal(0, 1, (n, h, w, c)))
+    # pooling out of, and into, channel slices of wider buffers
+    wide = torch.zeros((n, h, w, c + 24), dtype=h16(), device=dev)
+    wide[..., 8:8 + c] = dev_bf16(x, dev)
+    out = torch.full((n, h // 2, w // 2, c + 8), 7.0, dtype=h16(), device=dev)
+    L.check(lib.miseg_maxpool2x2_fwd(wide.data_ptr() + 16, out.data_ptr() + 16, n, h, w, c, c + 24, c + 8,
+                                     STORAGE["fmt"], None))
+    got = out.float().cpu().numpy()
+    np.testing.assert_array_equal(got[..., 8:], ops_np.maxpool2x2(x))
+    np.testing.assert_array_equal(got[..., :8], 7.0)
+    assert lib.miseg_maxpool2x2_fwd(wide.data_ptr(), out.data_ptr(), n, h + 1, w, c, c + 24, c + 8,
+                                    STORAGE["fmt"], None) < 0          # odd height
+    # image neighbourhoods
+    img = rng.random((n, h, w, 3)).astype(np.float32)
+    col = torch.full((n, h, w, 32), 9.0, dtype=h16(), device=dev)
+    L.check(lib.miseg_im2col3x3_fwd(dev_f32(img, dev).data_ptr(), col.data_ptr(), n, h, w, 9, STORAGE["fmt"], None))
+    pad = np.pad(img, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    want = np.zeros((n, h, w, 32), np.float32)
+    for ky in range(3):
+        for kx in range(3):
+            want[..., (ky * 3 + kx) * 3:(ky * 3 + kx) * 3 + 3] = pad[:, ky:ky + h, kx:kx + w, :]
+    np.testing.assert_array_equal(col.float().cpu().numpy(), bf16_round(want))
+    # the 3x3 'same' convolution of the image == the 1x1 convolution of the neighbourhood tensor
+    k = rng.normal(0, 0.2, (3, 3, 3, 64)).astype(np.float32)
+    w1 = np.zeros((1, 1, 32, 64), np.float32)
+    w1[0, 0, :27] = k.reshape(27, 64)
+    bias = rng.normal(0, 0.1, 64).astype(np.float32)
+    got, _ = run_conv(env, bf16_round(want), bf16_round(w1), shift=bias, act=L.ACT_RELU)
+    ref = np.maximum(ref_conv(bf16_round(img), bf16_round(k), 1, 1) + bias, 0)
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-2)
+    L.check(lib.miseg_im2col3x3_fwd(dev_f32(img, dev).data_ptr(), col.data_ptr(), n, h, w, 1, STORAGE["fmt"], None))
+    want1 = np.zeros((n, h, w, 32), np.float32)
+    want1[..., :3] = img
+    np.testing.assert_array_equal(col.float().cpu().numpy(), bf16_round(want1))
+    torch.cuda.synchronize()
+
+
 def test_collapse_and_loss_sums(env):
     from oracle import losses, post
     L, lib, dev = env

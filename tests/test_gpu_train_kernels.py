@@ -221,6 +221,19 @@ def test_pool_and_upsample_backward(env):
     dx = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device=dev)
     L.check(lib.miseg_maxpool3x3s2_bwd(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), n, h, w, c, c, c, c, None))
     np.testing.assert_allclose(dx.float().cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-2, atol=1e-2)
+    # 2x2 max pool (VGG), ties at zero again; then the ReLU backward of a Conv2D(activation="relu")
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.max_pool2d(xt, 2, 2).backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    L.check(lib.miseg_maxpool2x2_bwd(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), n, h, w, c, c, c, c, None))
+    np.testing.assert_array_equal(dx.float().cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy())
+    gfull = bf16_round(rng.normal(0, 1, (n, h, w, c)))
+    addend = bf16_round(rng.normal(0, 1, (n, h, w, c)))
+    gd, ad_ = dbf(gfull, dev), dbf(addend, dev)
+    L.check(lib.miseg_relu_bwd(xd.data_ptr(), gd.data_ptr(), None, dx.data_ptr(), n * h * w, c, c, c, 0, c, None))
+    np.testing.assert_array_equal(dx.float().cpu().numpy(), np.where(x > 0, gfull, 0))
+    L.check(lib.miseg_relu_bwd(xd.data_ptr(), gd.data_ptr(), ad_.data_ptr(), dx.data_ptr(), n * h * w, c, c, c, c,
+                               c, None))
+    np.testing.assert_array_equal(dx.float().cpu().numpy(), bf16_round(np.where(x > 0, gfull, 0) + addend))
     # average pool
     L.check(lib.miseg_avgpool2x2_bwd(dyd.data_ptr(), dx.data_ptr(), n, h, w, c, c, c, None))
     want = np.repeat(np.repeat(dy, 2, 1), 2, 2) / 4

@@ -35,6 +35,9 @@ CONFIGS = [
     ("densenet169", "FPN", 64, 64, 1),          # BASELINE config 5's network
     ("densenet169", "Linknet", 64, 64, 1),      # the reference's preferred model
     ("resnet50", "U-Net", 64, 64, 1),           # bottleneck units
+    ("vgg16", "U-Net", 64, 64, 1),              # biased convolutions with ReLU, 2x2 max pools, centre blocks
+    ("vgg16", "Linknet", 64, 64, 2),
+    ("vgg19", "FPN", 64, 64, 1),
 ]
 
 
@@ -91,7 +94,8 @@ def test_loss_and_head_gradients_vs_oracle(pkg):
         assert np.allclose(tr.moving[name][1].cpu().numpy(), mv, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("encoder,decoder,h,w,n", [("resnet18", "U-Net", 128, 192, 2), ("densenet121", "FPN", 64, 64, 2)])
+@pytest.mark.parametrize("encoder,decoder,h,w,n", [("resnet18", "U-Net", 128, 192, 2), ("densenet121", "FPN", 64, 64, 2),
+                                                  ("vgg16", "U-Net", 64, 96, 2)])
 def test_gradients_no_further_from_fp32_than_the_bf16_emulation(pkg, encoder, decoder, h, w, n):
     """End to end: every parameter gradient of one HIP training step against the fp32 oracle,
     with the oracle's bf16-storage emulation as the yardstick (see the module docstring)."""

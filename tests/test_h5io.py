@@ -80,7 +80,8 @@ def test_writer_reader_round_trip(pkg, tmp_path):
 
 
 @pytest.mark.parametrize("enc,dec,tss", [("resnet18", "U-Net", False), ("resnet34", "Linknet", True),
-                                         ("densenet121", "FPN", False), ("resnet50", "U-Net", False)])
+                                         ("densenet121", "FPN", False), ("resnet50", "U-Net", False),
+                                         ("vgg16", "Linknet", False)])
 def test_keras_layout_round_trip(pkg, tmp_path, enc, dec, tss):
     from miseg_amd import keras_h5, netspec, h5io
     from miseg_amd.model import Model
@@ -95,8 +96,9 @@ def test_keras_layout_round_trip(pkg, tmp_path, enc, dec, tss):
     names = [bytes(b).decode() for k in sorted(a for a in f["model_weights"].attrs if a.startswith("layer_names"))
              for b in f["model_weights"].attrs[k]]
     assert names == list(g.layers)
-    some = "conv1/conv" if enc.startswith("densenet") else "conv0"
-    assert f["model_weights"][some][some + "/kernel:0"].shape == (7, 7, 3, 64)
+    some = "conv1/conv" if enc.startswith("densenet") else "block1_conv1" if enc.startswith("vgg") else "conv0"
+    assert f["model_weights"][some][some + "/kernel:0"].shape == ((3, 3, 3, 64) if enc.startswith("vgg")
+                                                                  else (7, 7, 3, 64))
     m2 = keras_h5.load_keras_h5(path)
     assert m2.name == "AgNOR_test"
     assert (m2.graph.encoder, m2.graph.decoder, m2.graph.classes) == (enc, dec, 3)

@@ -72,7 +72,8 @@ def test_plan_records_and_validates_without_gpu(pkg):
     ("densenet169", "Linknet", 17051571), ("densenet169", "FPN", 15716035),
     # bottleneck ResNets: the two independently written builders (graph, oracle spec) must agree; the
     # totals are what they agree on, not published numbers
-    ("resnet50", "U-Net", 52490028), ("resnet101", "Linknet", 50266940), ("resnet152", "FPN", 61648204)])
+    ("resnet50", "U-Net", 52490028), ("resnet101", "Linknet", 50266940), ("resnet152", "FPN", 61648204),
+    ("vgg16", "U-Net", 33494435), ("vgg19", "FPN", 22884547)])
 def test_graph_param_counts_and_oracle_spec(pkg, enc, dec, total):
     from miseg_amd import netspec
     from oracle import nets
@@ -82,6 +83,20 @@ def test_graph_param_counts_and_oracle_spec(pkg, enc, dec, total):
     assert [(l, w, tuple(s)) for l, w, s, _ in g.weight_spec()] == \
         [(l, w, tuple(s)) for l, (_, ws) in spec.items() for w, s, _ in ws]
     assert [i for _, _, _, i in g.weight_spec()] == [i for _, (_, ws) in spec.items() for _, _, i in ws]
+
+
+def test_vgg_encoder_parameter_counts(pkg):
+    """keras_applications' documented totals without the classifier head: VGG16 14,714,688 and VGG19
+    20,024,384 parameters."""
+    from miseg_amd import netspec
+    for enc, total in (("vgg16", 14714688), ("vgg19", 20024384)):
+        g = netspec.build_graph(enc, "FPN", (64, 64, 3), 3)
+        assert sum(g.layers[n].count_params() for n in g.encoder_layers) == total
+        assert g.layers[g.encoder_output].cls == "MaxPooling2D"
+        assert [g.layers[n].out.c for n in g.skip_layers] == [512, 512, 256, 128, 64]
+    # U-Net and Linknet put two centre blocks between a pooled encoder output and the decoder
+    g = netspec.build_graph("vgg16", "U-Net", (64, 64, 3), 3)
+    assert "center_block2_relu" in g.layers and g.layers["decoder_stage4_concat"].out.c == 96
 
 
 def test_densenet_skips_resolve_by_keras_index(pkg):

@@ -36,6 +36,8 @@ def forward_errors(tr, weights):
             b = torch.from_numpy(weights[name]["bias"]) if "bias" in weights[name] else None
             ref = F.conv2d(xin.float().cpu().permute(0, 3, 1, 2), wt, b, stride=l.config["strides"],
                            padding=pad).permute(0, 2, 3, 1)
+            if l.config.get("activation") == "relu":
+                ref = torch.relu(ref)
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(ref))))
         elif l.cls == "Conv2DTranspose":
             xin, _ = tr.saved[name]
@@ -58,7 +60,10 @@ def forward_errors(tr, weights):
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), ref)))
         elif l.cls == "MaxPooling2D":
             xf = tr.saved[name].float().cpu().permute(0, 3, 1, 2)
-            ref = F.max_pool2d(F.pad(xf, (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1)
+            if l.config["pool_size"] == 2:
+                ref = F.max_pool2d(xf, 2, 2).permute(0, 2, 3, 1)
+            else:
+                ref = F.max_pool2d(F.pad(xf, (1, 1, 1, 1)), 3, 2).permute(0, 2, 3, 1)
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), ref)))
         elif l.cls == "AveragePooling2D":
             xf = tr.acts[l.inbound[0]].float().cpu().permute(0, 3, 1, 2)
@@ -136,7 +141,10 @@ def backward_errors(tr, weights, x_input):
             out.append((name, "dbeta", _rel(torch.from_numpy(gw[name]["beta"]), bet.grad)))
         elif l.cls == "MaxPooling2D":
             xf = nchw(tr.saved[name].float().cpu()).clone().requires_grad_(True)
-            F.max_pool2d(F.pad(xf, (1, 1, 1, 1)), 3, 2).backward(nchw(dyf))
+            if l.config["pool_size"] == 2:
+                F.max_pool2d(xf, 2, 2).backward(nchw(dyf))
+            else:
+                F.max_pool2d(F.pad(xf, (1, 1, 1, 1)), 3, 2).backward(nchw(dyf))
             out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xf.grad))))
         elif l.cls == "AveragePooling2D":
             xf = nchw(tr.acts[l.inbound[0]].float().cpu()).clone().requires_grad_(True)

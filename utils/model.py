@@ -94,7 +94,7 @@ def replace_model_input_shape(model, new_input_shape):
 
 def make_model(encoder, decoder, input_shape, classes, learning_rate, loss_function, metrics,
                encoder_freeze=False, model_name=None, use_tss=False, seed=None):
-    """Build and compile one of {resnet18/34/50/101/152, densenet121/169/201} x
+    """Build and compile one of {resnet18/34/50/101/152, densenet121/169/201, vgg16/19} x
     {"U-Net", "Linknet", "FPN"} with the hyper-parameters the reference fixes
     (decoder filters, batch-norm use, transpose blocks, pyramid sizes)."""
     graph = _netspec.build_graph(encoder, decoder, tuple(input_shape), classes,
