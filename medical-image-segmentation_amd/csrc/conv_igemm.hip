@@ -23,7 +23,7 @@ namespace MISEG_KNS {
 // prologue and layers whose Cin is not a multiple of 64.
 // ---------------------------------------------------------------------------------
 template <int WARPS_M, int WARPS_N, int MT, int NT, bool PRO>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WARPS_M * MT * 32;
   constexpr int BN = WARPS_N * NT * 32;
   constexpr int PA = BM / 64;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 // MFMAs of tile k run; one vmcnt(0) + barrier per K-step.
 // ---------------------------------------------------------------------------------
 template <int WARPS_M, int WARPS_N, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const ConvParams p) {
   constexpr int BM = WARPS_M * MT * 32;
   constexpr int BN = WARPS_N * NT * 32;
   constexpr int NA = BM / 32;  // A wave-instructions per wave per stage
@@ -655,25 +655,17 @@ static hipError_t launch_cfg(const ConvParams& p, dim3 grid, bool pro, bool dma,
   return hipGetLastError();
 }
 
-// heavy_edges: the layer has an operand prologue (every cout tile repeats it on the pixels it reads) or a
-// residual input (the epilogue's traffic grows with the tile count): such layers keep wide cout tiles
-static int choose_cfg(int M, int Cout, bool heavy_edges) {
+static int choose_cfg(int M, int Cout) {
   // Prefer the widest cout tile the layer fills, then the tallest pixel tile that still
-  // leaves at least ~2 blocks per CU.
+  // leaves at least ~2 blocks per CU.  (With two blocks resident per CU the 128x128 tile is within a few
+  // per cent of the best of all seven on 1x1, strided and Cin = 32 layers of 19 K .. 20 M pixels.)
   auto blocks = [&](int bm, int bn) {
     return (long long)((M + bm - 1) / bm) * ((Cout + bn - 1) / bn);
   };
   const long long want = 512;
   if (Cout > 64) {
-    // otherwise, measured on 1x1, strided and Cin = 32 layers of 19 K .. 20 M pixels: the 64-cout tiles
-    // beat the 128-cout ones (128x128, 64x128) by 1.2-1.6x at every size, the tall tile once there
-    // are several blocks per CU and wave
-    if (heavy_edges) {
-      if (blocks(128, 128) >= want) return 1;
-      if (blocks(64, 128) >= want) return 7;
-      return 4;
-    }
-    if (blocks(256, 64) >= 2048) return 2;
+    if (blocks(128, 128) >= want) return 1;
+    if (blocks(64, 128) >= want) return 7;
     return 4;
   }
   if (Cout > 32) {
@@ -828,7 +820,7 @@ static KernelChoice choose_kernel(const miseg_conv_desc* d) {
     return {K_HALO, 15};
   }
   const int M = d->N * d->Ho * d->Wo;
-  const int cfg = (hint >= 1 && hint <= 7) ? hint : choose_cfg(M, d->Cout, pro || d->residual != nullptr);
+  const int cfg = (hint >= 1 && hint <= 7) ? hint : choose_cfg(M, d->Cout);
   if (pro) return {K_REG_PRO, cfg};
   if ((d->Cin & 63) == 0 && !(d->tile_hint & MISEG_TILE_NO_DMA)) return {K_DMA, cfg};
   return {K_REG, cfg};
