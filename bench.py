@@ -75,15 +75,33 @@ def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
                                 "sample": "%d forward passes of 1 image 512x512x3, same network and cores" % n512}}
 
 
+PMC_FILES = {
+    # (images per plan, H, W, encoder, decoder) the counter passes were collected on -> reduced file
+    (4, 1920, 2560, "resnet34", "U-Net"): "r02_c_pmc_traffic.json",
+    (8, 1920, 2560, "densenet169", "Linknet"): "r02_c_pmc_traffic_d169_linknet.json",
+    (4, 1920, 2560, "densenet169", "FPN"): "r02_c_pmc_traffic_d169_fpn.json",
+    (16, 1920, 2560, "resnet18", "U-Net-train"): "r02_c_pmc_traffic_train_r18_unet.json",
+}
+
+
 def pmc_traffic(kernel, batch, h, w, encoder, decoder):
-    """HBM bytes per launch of `kernel` from the committed counter passes (collected with the same
-    command at batch 4, 1920x2560, ResNet-34 U-Net); None for any other configuration."""
-    path = os.path.join(ROOT, "profiles", "r02_b_pmc_traffic.json")
-    if not os.path.isfile(path) or (batch, h, w, encoder, decoder) != (4, 1920, 2560, "resnet34", "U-Net"):
+    """HBM bytes per launch of `kernel` from the committed counter passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE over the same command and configuration, reduced by scripts/pmc_traffic.py); None for a
+    configuration no pass was collected on."""
+    name = PMC_FILES.get((batch, h, w, encoder, decoder))
+    path = os.path.join(ROOT, "profiles", name) if name else None
+    if not path or not os.path.isfile(path):
         return None
     with open(path) as f:
-        k = json.load(f)["kernels"].get(kernel)
-    return k["hbm_bytes_per_launch"] if k else None
+        kernels = json.load(f)["kernels"]
+    k = kernels.get(kernel.split("(")[0])
+    if k:
+        return k["hbm_bytes_per_launch"]
+    # a name without template arguments stands for all its instantiations: mean over their launches
+    fam = [v for n, v in kernels.items() if n.split("<")[0] == kernel]
+    if not fam:
+        return None
+    return sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in fam) / sum(v["dispatches"] for v in fam)
 
 
 def training_leg(args, dev, rank, world, dist, h, w):
@@ -119,7 +137,8 @@ def training_leg(args, dev, rank, world, dist, h, w):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
-    roof = train_roofline(tr.profile_step(x, gt), 1e3 * elapsed / args.train_steps) if rank == 0 else None
+    roof = train_roofline(tr.profile_step(x, gt), 1e3 * elapsed / args.train_steps,
+                          (args.train_batch, h, w, args.train_encoder, args.decoder + "-train")) if rank == 0 else None
     del tr, x, gt
     torch.cuda.empty_cache()
     enc_names = {"resnet18": "ResNet-18", "resnet34": "ResNet-34", "densenet169": "DenseNet-169"}
@@ -137,7 +156,7 @@ def training_leg(args, dev, rank, world, dist, h, w):
             "peak_hbm_gib": peak, "roofline": roof}
 
 
-def train_roofline(prof, ms_per_step):
+def train_roofline(prof, ms_per_step, traffic_key=None):
     """`roofline` of the training leg from one step timed launch by launch (HIP events on each
     launch's own stream, Trainer.profile_step).  The dominant kernel is the one with the largest
     summed duration; convolution kernels are priced against the bf16 MFMA peak with their
@@ -162,7 +181,8 @@ def train_roofline(prof, ms_per_step):
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"]}
     head.update({
         "kernel": dom_name, "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
-        "timing": "HIP events around every launch of one step, on the launch's own stream", "traffic": None,
+        "timing": "HIP events around every launch of one step, on the launch's own stream",
+        "traffic": pmc_traffic(dom_name, *traffic_key) if traffic_key else None,
         "all_conv_launches": {"achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
                               "frac": conv_flops / (conv_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                               "gflop_per_step": conv_flops / 1e9, "ms_per_step": conv_ms,
@@ -243,7 +263,8 @@ def extra_config(encoder, decoder, classes, h, w, batch, streams, dev, storage, 
             "gflop_per_launch": dom["flops"] / dom["launches"] / 1e9,
             "achieved": dom["flops"] / (dom["ms"] * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": dom["flops"] / (dom["ms"] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-            "share_of_pass": dom["ms"] / op_ms.sum(), "traffic": None,
+            "share_of_pass": dom["ms"] / op_ms.sum(),
+            "traffic": pmc_traffic(dom_name, batch, h, w, encoder, decoder),
             "timing": "HIP events on the launch stream, one plan at a time (averaged over 3 passes)",
             "all_conv_launches": {"achieved": 2.0 * macs.sum() / (op_ms[conv].sum() * 1e-3) / 1e12,
                                   "frac": 2.0 * macs.sum() / (op_ms[conv].sum() * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
@@ -436,7 +457,7 @@ def main():
                 "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": pmc_traffic(dom_name, args.batch, h, w, args.encoder, args.decoder),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes), "
-                                "from the committed PMC passes profiles/r02_b_pmc_*.csv",
+                                "from the committed PMC passes profiles/r02_c_pmc_*.csv",
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                 "all_conv_launches": {
                     "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
