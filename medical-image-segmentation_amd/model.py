@@ -98,6 +98,7 @@ class Model:
         self.metrics = []
         self.encoder_freeze = False
         self._engines = {}
+        self._storage = "fp16"
 
     # ---- identity -----------------------------------------------------------
     @property
@@ -144,6 +145,7 @@ class Model:
     # ---- weights / config -----------------------------------------------------
     def _invalidate(self):
         self._engines = {}
+        self._storage = "fp16"          # new weights: the range check of __call__ starts over
 
     def get_weights(self):
         return W.to_list(self.graph, self.weights)
@@ -181,9 +183,36 @@ class Model:
         e = self._engines.get(batch)
         if e is None:
             self._engines = {}          # one resident plan at a time: buffers are per batch size
-            e = engine.Engine(self.graph, self.weights, batch=batch, device=self.device)
+            e = engine.Engine(self.graph, self.weights, batch=batch, device=self.device,
+                              storage=self._storage)
             self._engines[batch] = e
         return e
+
+    def _forward(self, batch):
+        """Inference forward pass on the engine.  The engine stores activations in fp16, whose range ends at
+        65504 (the kernels' conversions saturate there): activations of trained networks stay within a few
+        tens, a deep network with untrained weights may not.  The first batch a plan runs is therefore
+        followed by a look at the largest magnitude any of its 16-bit buffers holds; a plan that reached the
+        end of the range is replaced, from then on, by one with bf16 storage (fp32's range, 8 significand
+        bits), and the batch is run again."""
+        eng = self._engine(batch.shape[0])
+        probs = eng.forward(batch)
+        if eng.storage == "fp16" and not getattr(eng, "range_checked", False):
+            peak = 0.0
+            for t in eng._keep:
+                if t.dtype == torch.float16 and t.numel():
+                    lo, hi = torch.aminmax(t)
+                    peak = max(peak, abs(float(lo)), abs(float(hi)))
+            eng.range_checked = True
+            if not peak < 65000.0:          # saturated, or NaN
+                import warnings
+                warnings.warn("activations of %s reach the end of the fp16 range: its inference plans use bf16 "
+                              "storage from now on" % self.name)
+                self._storage = "bf16"
+                self._engines = {}
+                eng = self._engine(batch.shape[0])
+                probs = eng.forward(batch)
+        return eng, probs
 
     def __call__(self, batch, training=False):
         if isinstance(batch, DeviceArray):
@@ -195,8 +224,7 @@ class Model:
                 batch = torch.from_numpy(np.ascontiguousarray(np.asarray(batch, dtype=np.float32)))
             t = self._trainer(n)
             return DeviceArray(t.forward(batch.to(self.device, torch.float32), momentum_update=False).clone())
-        eng = self._engine(n)
-        probs = eng.forward(batch)
+        _, probs = self._forward(batch)
         return DeviceArray(probs.clone())
 
     def predict(self, x, batch_size=1, verbose=0):
@@ -209,10 +237,9 @@ class Model:
         """Forward + collapse_probabilities (utils/utils.py:50-68) on the device:
         returns uint8 (n,H,W,classes)."""
         n = batch.shape[0]
-        eng = self._engine(n)
-        if pixel_intensity != eng.collapse_value:
-            raise ValueError("the plan was built for pixel_intensity=%d" % eng.collapse_value)
-        eng.forward(batch)
+        if pixel_intensity != self._engine(n).collapse_value:
+            raise ValueError("the plan was built for pixel_intensity=%d" % self._engine(n).collapse_value)
+        eng, _ = self._forward(batch)
         return eng.mask[:n].cpu().numpy()
 
     def evaluate(self, dataset, return_dict=True, verbose=0, steps=None):

@@ -73,6 +73,26 @@ def test_deep_bottleneck_resnet_on_bf16_storage():
     check_engine("resnet101", "FPN", (64, 64), 1, 3, storage="bf16")
 
 
+def test_model_leaves_fp16_storage_when_the_range_overflows():
+    """The same network through the Model surface (`model(batch, training=False)`, /root/reference
+    utils/predict.py:159): the fp16 plan yields NaN, the model rebuilds its plan on bf16 storage, warns, and
+    returns the probabilities of that run."""
+    import miseg_amd
+    from miseg_amd import netspec
+    from miseg_amd.model import Model
+    from oracle import nets, ops_torch
+    g = netspec.build_graph("resnet101", "FPN", (64, 64, 3), 3)
+    weights = nets.init_weights(nets.build_spec("resnet101", "FPN", 3), seed=7, randomize_bn=True)
+    m = Model(g, weights=weights)
+    x = make_inputs(1, 64, 64)
+    with pytest.warns(UserWarning, match="fp16 range"):
+        got = m(x, training=False).numpy()
+    assert m._storage == "bf16" and np.isfinite(got).all()
+    np.testing.assert_allclose(got.sum(-1), 1.0, atol=1e-3)
+    masks = m.predict_masks(x)
+    assert masks.shape == (1, 64, 64, 3) and set(np.unique(masks)) <= {0, 127}
+
+
 def headline_agreement(storage, h=1920, w=2560, want=None, x=None, weights=None):
     """ResNet-34 U-Net, 3 classes, h x w x 3 (BASELINE config 2), seeded random-init weights with
     randomised BatchNorm statistics, nothing rescaled.  Returns (share of pixels whose mask equals
