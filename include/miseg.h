@@ -434,10 +434,11 @@ int miseg_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, int64_t pix
                             const void* addend, int32_t addend_pix_stride, void* stream);
 
 /* dx of ZeroPadding2D(1)+MaxPooling2D(3,2): the gradient goes to the first maximum of each
- * window in row-major scan order.  x: pool input [N,H,W,C], dy: [N,H/2,W/2,C], bf16. */
+ * window in row-major scan order.  x: pool input [N,H,W,C], dy: [N,H/2,W/2,C], bf16.  addend (may be NULL):
+ * a gradient the pool's input already holds (same extents as x), added to the result. */
 int miseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
                            int32_t C, int32_t x_pix_stride, int32_t dy_pix_stride,
-                           int32_t dx_pix_stride, void* stream);
+                           int32_t dx_pix_stride, const void* addend, int32_t addend_pix_stride, void* stream);
 /* MaxPooling2D(2, strides=2) of the keras_applications VGG encoders (the block*_pool layers the reference
  * reaches through sm.Unet/Linknet/FPN(backbone_name="vgg16"), /root/reference utils/model.py:176-211).
  * in [N,H,W,C] -> out [N,H/2,W/2,C], 16-bit in storage format fmt; H, W even. */

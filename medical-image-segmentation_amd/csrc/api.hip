@@ -45,8 +45,8 @@ int launch_resize_nearest_u8(const unsigned char*, unsigned char*, int, int, int
 int launch_one_hot(const unsigned char*, float*, long long, int, hipStream_t);
 int launch_augment(const float*, const float*, float*, float*, int, int, int, int, const float*, double*,
                    hipStream_t);
-int launch_maxpool3x3s2_bwd(const void*, const void*, void*, int, int, int, int, int, int, int,
-                            hipStream_t);
+int launch_maxpool3x3s2_bwd(const void*, const void*, void*, int, int, int, int, int, int, int, const void*,
+                            int, hipStream_t);
 int launch_avgpool2x2_bwd(const void*, void*, int, int, int, int, int, int, hipStream_t);
 int launch_maxpool2x2_bwd(const void*, const void*, void*, int, int, int, int, int, int, int, hipStream_t);
 int launch_relu_bwd(const void*, const void*, const void*, void*, long long, int, int, int, int, int,
@@ -362,8 +362,9 @@ int miseg_augment(const float* img, const float* mask, float* img_out, float* ma
                         (hipStream_t)stream);
 }
 int miseg_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int32_t N, int32_t H, int32_t W,
-                           int32_t C, int32_t xps, int32_t dps, int32_t ops, void* stream) {
-  return launch_maxpool3x3s2_bwd(x, dy, dx, N, H, W, C, xps, dps, ops, (hipStream_t)stream);
+                           int32_t C, int32_t xps, int32_t dps, int32_t ops, const void* addend, int32_t aps,
+                           void* stream) {
+  return launch_maxpool3x3s2_bwd(x, dy, dx, N, H, W, C, xps, dps, ops, addend, aps, (hipStream_t)stream);
 }
 int miseg_maxpool2x2_fwd(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C,
                          int32_t ips, int32_t ops, int32_t fmt, void* stream) {

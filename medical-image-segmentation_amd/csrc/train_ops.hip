@@ -421,9 +421,10 @@ int launch_channel_sums(const void* x, long long pixels, int C, int ps, double* 
 // One thread owns a 2x2 block of input pixels (rows 2a, 2a+1; columns 2b, 2b+1) and 8 channels.
 // The windows that can route a gradient into the block are (a..a+1) x (b..b+1); together they
 // cover the 5x5 patch of rows 2a-1..2a+3, which is loaded once.
+// addend (may be null): a gradient the pool's input already holds, added to the result.
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                         bf16_t* __restrict__ dx, int N, int H, int W, int C, int xps,
-                                        int dps, int ops) {
+                                        int dps, int ops, const bf16_t* __restrict__ addend, int aps) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, C8 = C >> 3;
   const int Hb = (H + 1) / 2, Wb = (W + 1) / 2;
   const long long total = (long long)N * Hb * Wb * C8;
@@ -500,21 +501,29 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __r
 #pragma unroll
       for (int qx = 0; qx < 2; ++qx) {
         const int iy = 2 * by + qy, ix = 2 * bx + qx;
-        if (iy < H && ix < W)
+        if (iy < H && ix < W) {
+          if (addend) {
+            float a[8];
+            unpack8f(a, *reinterpret_cast<const uint4*>(addend + (((long long)n * H + iy) * W + ix) * aps + c8 * 8));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[qy][qx][j] += a[j];
+          }
           *reinterpret_cast<uint4*>(dx + (((long long)n * H + iy) * W + ix) * ops + c8 * 8) = pack8f(acc[qy][qx]);
+        }
       }
   }
 }
 
 int launch_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C,
-                            int xps, int dps, int ops, hipStream_t s) {
+                            int xps, int dps, int ops, const void* addend, int aps, hipStream_t s) {
   MISEG_CHECK_ARG(x && dy && dx, "maxpool_bwd: null pointer");
   MISEG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0 && (xps & 7) == 0 &&
-                      (dps & 7) == 0 && (ops & 7) == 0,
+                      (dps & 7) == 0 && (ops & 7) == 0 && (!addend || (aps & 7) == 0),
                   "maxpool_bwd: C and strides must be multiples of 8");
   const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C >> 3);
   hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_cap(total, 256, 16384)), dim3(256), 0, s,
-                     (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, xps, dps, ops);
+                     (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C, xps, dps, ops,
+                     (const bf16_t*)addend, aps);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
 }

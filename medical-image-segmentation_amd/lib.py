@@ -127,7 +127,7 @@ SIGNATURES = {
                                            C.c_float, _I32, _VP, _VP]),
     "miseg_bn_relu_bwd_apply": (C.c_int, [_VP, _VP, _VP, _I64, _I32, _I32, _I32, _I32, _FP, _FP, _FP,
                                           _FP, C.c_float, _I32, _VP, _VP, _I32, _VP]),
-    "miseg_maxpool3x3s2_bwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
+    "miseg_maxpool3x3s2_bwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _I32, _VP]),
     "miseg_avgpool2x2_bwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_maxpool2x2_fwd": (C.c_int, [_VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_maxpool2x2_bwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP]),

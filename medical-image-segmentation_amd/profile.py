@@ -23,7 +23,7 @@ BYTES = {
     "miseg_copy_channels": lambda a: a[3] * a[4] * 2 * (2 + (1 if a[1] else 0)),
     "miseg_channel_sums": lambda a: a[1] * a[2] * 2,
     "miseg_maxpool3x3s2_fwd": lambda a: a[4] * a[5] * a[6] * a[7] * 2 * 1.25,
-    "miseg_maxpool3x3s2_bwd": lambda a: a[3] * a[4] * a[5] * a[6] * 2 * 2.25,
+    "miseg_maxpool3x3s2_bwd": lambda a: a[3] * a[4] * a[5] * a[6] * 2 * (2.25 + (1 if a[10] else 0)),
     "miseg_avgpool2x2_fwd": lambda a: a[2] * a[3] * a[4] * a[5] * 2 * 1.25,
     "miseg_avgpool2x2_bwd": lambda a: a[2] * a[3] * a[4] * a[5] * 2 * 1.25,
     "miseg_loss_sums": lambda a: a[3] * a[4] * 8,

@@ -385,18 +385,33 @@ class Trainer:
         self.lib.note(buf.value.decode(), macs, nbytes)
 
     def _stats_for(self, name, cout):
-        """The statistics buffer of the BatchNormalization that is the only consumer of convolution
-        `name` (zeroed, and remembered so that the BatchNormalization only finalises), else None."""
-        cons = self.consumers.get(name, [])
-        if len(cons) != 1 or cout % 8 or os.environ.get("MISEG_NO_FUSED_STATS"):
+        """The statistics buffer of the one BatchNormalization among the consumers of tensor `name`
+        (zeroed, and remembered so that the BatchNormalization only finalises), else None."""
+        bns = [c for c in self.consumers.get(name, []) if self.g.layers[c].cls == "BatchNormalization"]
+        if len(bns) != 1 or cout % 8 or os.environ.get("MISEG_NO_FUSED_STATS"):
             return None
-        bn = self.g.layers[cons[0]]
-        if bn.cls != "BatchNormalization" or bn.name in self.frozen or bn.name not in self.bn_state:
+        bn = self.g.layers[bns[0]]
+        if bn.name in self.frozen or bn.name not in self.bn_state:
             return None
         buf = self.bn_state[bn.name]["fused"]
         buf.zero_()
         self.fused_stats.add(bn.name)
         return buf
+
+    def _add_to_fuse(self, name):
+        """The Add layer that is the only consumer of convolution `name` and whose other input has been
+        computed already (the shortcut of a residual unit), else None."""
+        cons = self.consumers.get(name, [])
+        if len(cons) != 1 or os.environ.get("MISEG_NO_FUSED_ADD"):
+            return None
+        add = self.g.layers[cons[0]]
+        if add.cls != "Add" or len(add.inbound) != 2 or add.inbound[0] == add.inbound[1]:
+            return None
+        other = [i for i in add.inbound if i != name][0]
+        o = self.acts.get(other)
+        if o is None or (o.h, o.w, o.c) != (add.out.h, add.out.w, add.out.c):
+            return None
+        return add.name
 
     def wgrad(self, x, dy_ptr, dy_strides, dw_ptr, cin, cout, kh, kw, sy, sx, py, px, ho, wo,
               x_geom=None, dy_t=None):
@@ -508,6 +523,7 @@ class Trainer:
         self.saved = {}
         self.concat_bufs = {}
         self.fused_stats = set()
+        self.fused_adds = set()
         n = self.n
         self.x_in = x.contiguous()
         for name in self.order:
@@ -556,6 +572,19 @@ class Trainer:
                               l.out.w, bias=bias, act=act, probs=probs,
                               temperature=g.temperature if g.temperature else 1.0)
                     self.probs = probs
+                    self.saved[name] = (xin, pad)
+                    continue
+                add = self._add_to_fuse(name) if not relu else None
+                if add is not None:
+                    # Add([this convolution, a tensor that exists already]): the addition happens in the
+                    # epilogue (as do the statistics of a BatchNormalization that follows the Add), and the
+                    # convolution's own output is never stored
+                    other = [i for i in g.layers[add].inbound if i != name][0]
+                    out = self.new_out(add, l.out.h, l.out.w, co)
+                    self.conv(xin, self.wptr(name), co, k, k, stride, stride, pad, pad, out, l.out.h, l.out.w,
+                              bias=bias, residual=self.acts[other], stats=self._stats_for(add, co))
+                    self.acts[add] = out
+                    self.fused_adds.add(add)
                     self.saved[name] = (xin, pad)
                     continue
                 out = self.new_out(name, l.out.h, l.out.w, co)
@@ -636,6 +665,8 @@ class Trainer:
                                                            shift, xin.pix, 0, out.pix, st))
                 self.acts[name] = out
             elif cls == "Add":
+                if name in self.fused_adds:
+                    continue
                 a, b = self.acts[l.inbound[0]], self.acts[l.inbound[1]]
                 self.acts[name] = self.add_into(a, b, l.out.c, out=self.new_out(name, l.out.h, l.out.w, l.out.c))
             elif cls == "Concatenate":
@@ -816,14 +847,20 @@ class Trainer:
                 self._fused_dgrad(grads, l.inbound[0], name, dy, run)
             elif cls == "MaxPooling2D":
                 xin = self.saved[name]
-                dx = self.new(xin.h, xin.w, xin.c)
                 if l.config["pool_size"] == 2:
+                    dx = self.new(xin.h, xin.w, xin.c)
                     L.check(lib.miseg_maxpool2x2_bwd(xin.ptr, dy.ptr, dx.ptr, n, xin.h, xin.w, xin.c, xin.pix,
                                                      dy.pix, dx.pix, st))
+                    self._accum(grads, self._src(l.inbound[0])[0], dx, name, dy)
                 else:
-                    L.check(lib.miseg_maxpool3x3s2_bwd(xin.ptr, dy.ptr, dx.ptr, n, xin.h, xin.w, xin.c, xin.pix,
-                                                       dy.pix, dx.pix, st))
-                self._accum(grads, self._src(l.inbound[0])[0], dx, name, dy)
+                    def run(res, xin=xin, dy=dy):
+                        out = self.new(xin.h, xin.w, xin.c)
+                        L.check(lib.miseg_maxpool3x3s2_bwd(xin.ptr, dy.ptr, out.ptr, n, xin.h, xin.w, xin.c, xin.pix,
+                                                           dy.pix, out.pix, res.ptr if res is not None else None,
+                                                           res.pix if res is not None else 0, st))
+                        return out
+                    # the gradient the pool's input already holds (a skip connection's) is added in the kernel
+                    self._fused_dgrad(grads, self._src(l.inbound[0])[0], name, dy, run)
             elif cls == "AveragePooling2D":
                 src = g.layers[l.inbound[0]].out
                 dx = self.new(src.h, src.w, src.c)

@@ -219,8 +219,14 @@ def test_pool_and_upsample_backward(env):
     F.max_pool2d(xp, 3, 2).backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
     xd, dyd = dbf(x, dev), dbf(dy, dev)
     dx = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device=dev)
-    L.check(lib.miseg_maxpool3x3s2_bwd(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), n, h, w, c, c, c, c, None))
+    L.check(lib.miseg_maxpool3x3s2_bwd(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), n, h, w, c, c, c, c, None, 0, None))
     np.testing.assert_allclose(dx.float().cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy(), rtol=1e-2, atol=1e-2)
+    held = bf16_round(rng.normal(0, 1, (n, h, w, c)))          # a gradient the input already holds
+    hd = dbf(held, dev)
+    L.check(lib.miseg_maxpool3x3s2_bwd(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), n, h, w, c, c, c, c,
+                                       hd.data_ptr(), c, None))
+    np.testing.assert_allclose(dx.float().cpu().numpy(), xt.grad.permute(0, 2, 3, 1).numpy() + held, rtol=1e-2,
+                               atol=2e-2)
     # 2x2 max pool (VGG), ties at zero again; then the ReLU backward of a Conv2D(activation="relu")
     xt = torch.from_numpy(x).permute(0, 3, 1, 2).clone().requires_grad_(True)
     F.max_pool2d(xt, 2, 2).backward(torch.from_numpy(dy).permute(0, 3, 1, 2))

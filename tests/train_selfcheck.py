@@ -29,16 +29,18 @@ def grads_as_weights(tr):
 def forward_errors(tr, weights):
     g = tr.g
     out = []
+
+    def conv_ref(name):
+        l = g.layers[name]
+        xin, pad = tr.saved[name]
+        wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1)
+        b = torch.from_numpy(weights[name]["bias"]) if "bias" in weights[name] else None
+        ref = F.conv2d(xin.float().cpu().permute(0, 3, 1, 2), wt, b, stride=l.config["strides"],
+                       padding=pad).permute(0, 2, 3, 1)
+        return torch.relu(ref) if l.config.get("activation") == "relu" else ref
     for name, l in g.layers.items():
         if l.cls == "Conv2D" and name in tr.acts and l.config["kernel_size"] != 7:
-            xin, pad = tr.saved[name]
-            wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1)
-            b = torch.from_numpy(weights[name]["bias"]) if "bias" in weights[name] else None
-            ref = F.conv2d(xin.float().cpu().permute(0, 3, 1, 2), wt, b, stride=l.config["strides"],
-                           padding=pad).permute(0, 2, 3, 1)
-            if l.config.get("activation") == "relu":
-                ref = torch.relu(ref)
-            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(ref))))
+            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(conv_ref(name)))))
         elif l.cls == "Conv2DTranspose":
             xin, _ = tr.saved[name]
             wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1)
@@ -53,8 +55,10 @@ def forward_errors(tr, weights):
                              + torch.from_numpy(weights[name]["beta"]))
             out.append((name, "fwd", _rel(tr.acts[tr.consumers[name][0]].float().cpu(), _bf(ref))))
         elif l.cls == "Add":
-            ref = _bf(tr.acts[l.inbound[0]].float().cpu() + tr.acts[l.inbound[1]].float().cpu())
-            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), ref)))
+            # an input the trainer never stored is a convolution whose epilogue did the addition: its
+            # (unrounded) result enters the reference instead
+            parts = [tr.acts[i].float().cpu() if i in tr.acts else conv_ref(i) for i in l.inbound]
+            out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(parts[0] + parts[1]))))
         elif l.cls == "Concatenate":
             ref = torch.cat([tr.acts[i].float().cpu() for i in l.inbound], dim=-1)
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), ref)))
