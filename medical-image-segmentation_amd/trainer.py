@@ -366,7 +366,9 @@ class Trainer:
         d.act = act
         d.transposed = int(transposed)          # True/1: transpose conv; 2: its data gradient
         d.temperature = temperature
-        if stats is not None:
+        if isinstance(stats, tuple):              # (address, stride): a channel slice of a wider statistics buffer
+            d.stats, d.stats_replicas, d.stats_stride = stats[0], STAT_REPLICAS, stats[1]
+        elif stats is not None:
             d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), STAT_REPLICAS, _c32(cout)
         self._note_conv(d, x, probs is not None, residual is not None)
         L.check(self.lib.miseg_conv2d_fwd(C.byref(d), self.stream()))
@@ -397,6 +399,57 @@ class Trainer:
         buf.zero_()
         self.fused_stats.add(bn.name)
         return buf
+
+    def _concat_root(self, name):
+        """(outermost Concatenate buffer that tensor `name` lives in, channel offset there) or (None, 0)."""
+        c0, root = 0, name
+        while root in self.place:
+            root, off = self.place[root]
+            c0 += off
+        if root == name or self.g.layers[root].cls != "Concatenate":
+            return None, 0
+        return root, c0
+
+    def _cat_stats(self, root):
+        """Per-channel sum / sum of squares of everything written into concatenated buffer `root` so far
+        (DenseNet: every layer normalises the whole prefix of its block again; the batch statistics of a
+        channel do not change once it is written, so they are gathered once, by the epilogue of the
+        convolution that produces the channel).  Layout as the per-layer buffers: STAT_REPLICAS + 1 slots
+        of [2][stride] doubles."""
+        buf = self.cat_stats.get(root)
+        if buf is None:
+            stride = _c32(self.g.layers[root].out.c)
+            buf = self.cat_stats[root] = torch.zeros((STAT_REPLICAS + 1, 2, stride), dtype=torch.float64,
+                                                     device=self.dev)
+        return buf
+
+    def _cat_stats_for(self, name, cout):
+        """Statistics destination for convolution `name` when its output is a channel slice of a concatenated
+        buffer whose statistics are being kept (see _cat_stats), else None."""
+        root, c0 = self._concat_root(name)
+        if root is None or root not in self.cat_seeded or cout % 8 or os.environ.get("MISEG_NO_FUSED_STATS"):
+            return None
+        buf = self._cat_stats(root)
+        return (buf.data_ptr() + 8 * c0, buf.shape[2])
+
+    def _nested_concats(self, root):
+        """Names of the Concatenate layers that live at offset 0 of buffer `root` (DenseNet's growing prefix)."""
+        return [n for n, (r, off) in self.place.items() if off == 0 and self.g.layers[n].cls == "Concatenate" and
+                self._concat_root(n)[0] == root]
+
+    def _grows_by_convs(self, root, first):
+        """Is every tensor of buffer `root` other than `first` the output of a convolution whose epilogue can
+        gather statistics (no ReLU of its own, a multiple of 8 channels)?"""
+        for n, _ in self.place.items():
+            if n == first or self._concat_root(n)[0] != root:
+                continue
+            l = self.g.layers[n]
+            if l.cls == "Concatenate":
+                continue
+            if l.cls != "Conv2D" or l.config.get("activation") == "relu" or l.out.c % 8 or \
+                    l.config["kernel_size"] == 7:
+                return False
+        return True
 
     def _add_to_fuse(self, name):
         """The Add layer that is the only consumer of convolution `name` and whose other input has been
@@ -524,6 +577,8 @@ class Trainer:
         self.concat_bufs = {}
         self.fused_stats = set()
         self.fused_adds = set()
+        self.cat_stats = {}
+        self.cat_seeded = set()
         n = self.n
         self.x_in = x.contiguous()
         for name in self.order:
@@ -588,9 +643,13 @@ class Trainer:
                     self.saved[name] = (xin, pad)
                     continue
                 out = self.new_out(name, l.out.h, l.out.w, co)
+                stats = None
+                if not relu:
+                    stats = self._stats_for(name, co)
+                    if stats is None:
+                        stats = self._cat_stats_for(name, co)
                 self.conv(xin, self.wptr(name), co, k, k, stride, stride, pad, pad, out, l.out.h, l.out.w,
-                          bias=bias, stats=None if relu else self._stats_for(name, co),
-                          act=L.ACT_RELU if relu else L.ACT_NONE)
+                          bias=bias, stats=stats, act=L.ACT_RELU if relu else L.ACT_NONE)
                 self.acts[name] = out
                 self.saved[name] = (xin, pad)
             elif cls == "Conv2DTranspose":
@@ -615,12 +674,36 @@ class Trainer:
                         mm.data_ptr() if mm is not None else None, mv.data_ptr() if mv is not None else None,
                         l.config["momentum"], l.config["epsilon"], s["mean"].data_ptr(), s["var"].data_ptr(),
                         s["scale"].data_ptr(), s["shift"].data_ptr(), st))
+                elif l.inbound[0] in self.cat_seeded:
+                    # the input is a concatenated buffer whose channels all brought their statistics along
+                    buf = self.cat_stats[l.inbound[0] if l.inbound[0] in self.cat_stats else
+                                         self._concat_root(l.inbound[0])[0]]
+                    L.check(lib.miseg_bn_finalize(
+                        buf.data_ptr(), STAT_REPLICAS, buf.shape[2], xin.pixels, c, gamma,
+                        self.view(name, "beta").data_ptr(),
+                        mm.data_ptr() if mm is not None else None, mv.data_ptr() if mv is not None else None,
+                        l.config["momentum"], l.config["epsilon"], s["mean"].data_ptr(), s["var"].data_ptr(),
+                        s["scale"].data_ptr(), s["shift"].data_ptr(), st))
                 else:
                     L.check(lib.miseg_bn_stats_fwd(
                         xin.ptr, xin.pixels, c, xin.pix, gamma, self.view(name, "beta").data_ptr(),
                         mm.data_ptr() if mm is not None else None, mv.data_ptr() if mv is not None else None,
                         l.config["momentum"], l.config["epsilon"], s["mean"].data_ptr(), s["var"].data_ptr(),
                         s["scale"].data_ptr(), s["shift"].data_ptr(), s["ws"].data_ptr(), st))
+                    root, c0 = self._concat_root(l.inbound[0])
+                    if root is not None and c0 == 0 and not os.environ.get("MISEG_NO_FUSED_STATS") and \
+                            self._grows_by_convs(root, l.inbound[0]):
+                        # the first tensor of a concatenated buffer that convolutions then extend (the input
+                        # of a DenseNet block): its statistics, just computed, seed the buffer's
+                        buf = self._cat_stats(root)
+                        buf.zero_()
+                        npx = float(xin.pixels)
+                        mean64, var64 = s["mean"][:c].double(), s["var"][:c].double()
+                        buf[0, 0, :c] = mean64 * npx
+                        buf[0, 1, :c] = (var64 + mean64 * mean64) * npx
+                        self.cat_seeded.add(root)
+                        for nm in self._nested_concats(root):
+                            self.cat_seeded.add(nm)
                 cons = self.consumers[name]
                 relu = len(cons) == 1 and g.layers[cons[0]].cls == "Activation" and \
                     g.layers[cons[0]].config["activation"] == "relu"
