@@ -135,7 +135,7 @@ typedef struct miseg_conv_desc {
    * BatchNormalization (fused into the epilogue instead of a second pass over the tensor):
    * double[stats_replicas + 1][2][stats_stride], zeroed by the caller; the kernel ADDS sum(v) to
    * [r][0][c] and sum(v*v) to [r][1][c], r = block index mod stats_replicas (the last slot is
-   * where miseg_bn_finalize puts the totals).  Needs a bf16
+   * spare).  Needs a bf16
    * `out`, Cout % 8 == 0 and 16-byte aligned output strides.  miseg_bn_finalize reduces it. */
   void* stats;
   int32_t stats_replicas;

@@ -130,15 +130,33 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, long long co
   }
 }
 
-// sums[r][2][stride] -> out[2][C]
-__global__ void bn_reduce_replicas_kernel(const double* __restrict__ stats, int replicas, int stride,
-                                          int C, double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
-  const int which = i / C, c = i - which * C;
-  double t = 0.0;
-  for (int r = 0; r < replicas; ++r) t += stats[((long long)r * 2 + which) * stride + c];
-  out[i] = t;
+// The same from the replicated sums a convolution's epilogue gathered: stats[r][2][stride], r < replicas.
+__global__ void bn_finalize_replicas_kernel(const double* __restrict__ stats, int replicas, int stride,
+                                            long long count, int C, const float* __restrict__ gamma,
+                                            const float* __restrict__ beta, float* moving_mean, float* moving_var,
+                                            float momentum, float eps, float* mean, float* var, float* scale,
+                                            float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < replicas; ++r) {
+    s1 += stats[((long long)r * 2 + 0) * stride + c];
+    s2 += stats[((long long)r * 2 + 1) * stride + c];
+  }
+  const double m = s1 / (double)count;
+  double v = s2 / (double)count - m * m;
+  if (v < 0) v = 0;
+  mean[c] = (float)m;
+  var[c] = (float)v;
+  const float inv = 1.0f / sqrtf((float)v + eps);
+  const float sc = gamma ? gamma[c] * inv : inv;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)m * sc;
+  if (moving_mean) {
+    const double unbiased = count > 1 ? v * (double)count / (double)(count - 1) : v;
+    moving_mean[c] = momentum * moving_mean[c] + (1.f - momentum) * (float)m;
+    moving_var[c] = momentum * moving_var[c] + (1.f - momentum) * (float)unbiased;
+  }
 }
 
 int launch_bn_finalize(const double* stats, int replicas, int stride, long long pixels, int C,
@@ -147,12 +165,8 @@ int launch_bn_finalize(const double* stats, int replicas, int stride, long long 
   MISEG_CHECK_ARG(stats && beta && mean && var && scale && shift, "bn_finalize: null pointer");
   MISEG_CHECK_ARG(pixels > 0 && C > 0 && replicas > 1 && stride >= C, "bn_finalize: bad extents");
   MISEG_CHECK_ARG((mm == nullptr) == (mv == nullptr), "bn_finalize: moving stats go together");
-  // the buffer has replicas + 1 slots of [2][stride] doubles; the last one receives the totals
-  double* tot = const_cast<double*>(stats) + (long long)replicas * 2 * stride;
-  hipLaunchKernelGGL(bn_reduce_replicas_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, s, stats, replicas,
-                     stride, C, tot);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, tot, pixels, C, gamma,
-                     beta, mm, mv, momentum, eps, mean, var, scale, shift);
+  hipLaunchKernelGGL(bn_finalize_replicas_kernel, dim3((C + 63) / 64), dim3(64), 0, s, stats, replicas, stride,
+                     pixels, C, gamma, beta, mm, mv, momentum, eps, mean, var, scale, shift);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
 }
