@@ -108,6 +108,11 @@ def load_keras_h5(path, model_cls=None):
     g = netspec.build_graph(arch["encoder"], arch["decoder"], arch["input_shape"], arch["classes"],
                             activation=arch["activation"], temperature=arch["temperature"], name=arch["name"])
     model = (model_cls or Model)(g, weights=read_weights(f, g))
+    # a model saved with a frozen encoder comes back frozen: every weighted backbone layer non-trainable
+    by_name = {(l.get("name") or l["config"]["name"]): l["config"] for l in
+               json.loads(_text(cfg)).get("config", {}).get("layers", [])}
+    weighted = [n for n in g.encoder_layers if g.layers[n].weights]
+    model.encoder_freeze = bool(weighted) and all(by_name.get(n, {}).get("trainable", True) is False for n in weighted)
     return model
 
 
@@ -169,8 +174,14 @@ def _keras_layer_config(l):
 def keras_model_config(model):
     g = model.graph
     layers = []
+    # encoder_freeze (utils/model.py:179,191,203 -> segmentation_models freeze_model): the backbone's layers
+    # carry trainable = False in the saved config
+    frozen = set(g.encoder_layers) if getattr(model, "encoder_freeze", False) else set()
     for l in g.layers.values():
-        layers.append({"class_name": l.cls, "config": _keras_layer_config(l), "name": l.name,
+        cfg = _keras_layer_config(l)
+        if l.name in frozen and l.cls != "InputLayer":
+            cfg["trainable"] = False
+        layers.append({"class_name": l.cls, "config": cfg, "name": l.name,
                        "inbound_nodes": [[[n, 0, 0, {}] for n in l.inbound]] if l.inbound else []})
     first, last = layers[0]["name"], layers[-1]["name"]
     return {"class_name": "Functional",

@@ -145,3 +145,25 @@ def test_load_model_sniffs_format_and_reports_mismatch(pkg, tmp_path):
     w.save(bad)
     with pytest.raises(ValueError, match="bn_data|conv0"):
         um.load_model(bad, compile=False)
+
+
+def test_frozen_encoder_survives_the_round_trip(pkg, tmp_path):
+    """encoder_freeze is stored as the backbone layers' `trainable` flags (as Keras stores it) and read back."""
+    from miseg_amd import keras_h5, netspec
+    from miseg_amd.model import Model
+    from miseg_amd import weights as W
+    import json
+    from miseg_amd import h5io
+    g = netspec.build_graph("resnet18", "Linknet", (64, 64, 3), 3)
+    m = Model(g, weights=W.init_weights(g, seed=2))
+    m.encoder_freeze = True
+    path = os.path.join(str(tmp_path), "frozen.h5")
+    keras_h5.save_keras_h5(m, path)
+    cfg = json.loads(keras_h5._text(h5io.File(path).attrs["model_config"]))["config"]["layers"]
+    flags = {l["name"]: l["config"].get("trainable", True) for l in cfg}
+    assert flags["stage3_unit1_conv1"] is False and flags["bn_data"] is False
+    assert flags["decoder_stage0a_conv"] is True and flags["final_conv"] is True
+    assert keras_h5.load_keras_h5(path).encoder_freeze is True
+    m.encoder_freeze = False
+    keras_h5.save_keras_h5(m, path)
+    assert keras_h5.load_keras_h5(path).encoder_freeze is False
