@@ -264,8 +264,9 @@ class Engine:
         if out is None:
             out = self.buf((x.h), x.w, _ceil32(cout)).slice(0, cout)
         s, t = self.bn_fold(base + "_bn")
-        self.conv(base, x, self.conv_weight(base + "_conv"), cout, k, pad=(k - 1) // 2, out=out,
-                  scale=s, shift=t, act=L.ACT_RELU)
+        # x may carry zero channels beyond the layer's own (padding to what a kernel takes)
+        self.conv(base, x, self.conv_weight(base + "_conv", cin_pad=_ceil32(x.c)), cout, k, pad=(k - 1) // 2,
+                  out=out, scale=s, shift=t, act=L.ACT_RELU)
         self.taps[base + "_relu"] = out
         return out
 
@@ -557,7 +558,9 @@ class Engine:
             for i, f in enumerate((512, 256, 128, 64, 32)):
                 h, w = 2 * h, 2 * w
                 sc = skip_syms[i].c if i < len(skip_syms) else 0
-                cb = self.buf(h, w, _ceil32(f + sc))
+                # more than 32 channels: padded (zero channels, zero weights) to a multiple of 64, which is
+                # what the LDS-DMA kernels take (VGG's last stage concatenates 32 + 64)
+                cb = self.buf(h, w, _ceil32(f + sc) if f + sc <= 32 else (f + sc + 63) // 64 * 64)
                 concat.append(cb)
                 if sc:
                     skip_dst[skip_names[i]] = cb.slice(f, sc)
@@ -583,7 +586,7 @@ class Engine:
                     self._unet_tail("decoder_stage4b", xin, "final_conv")
                     x = None
                 else:
-                    x = self.conv_bn_relu("decoder_stage%db" % i, xin, 3)
+                    x = self.conv_bn_relu("decoder_stage%db" % i, cb, 3)
             if x is not None:
                 self._head("final_conv", x)
         elif dec == "Linknet":
