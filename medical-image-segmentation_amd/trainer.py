@@ -738,12 +738,24 @@ class Trainer:
                 self.acts[name] = out
             elif cls == "UpSampling2D":
                 xin = self.acts[l.inbound[0]]
-                out = self.new_out(name, l.out.h, l.out.w, l.out.c)
+                out = self.new_out(name, l.out.h, l.out.w, l.out.c) if self._add_to_fuse(name) is None or \
+                    l.config["interpolation"] == "bilinear" else None
                 if l.config["interpolation"] == "bilinear":
                     L.check(lib.miseg_upsample_bilinear2x_fwd(xin.ptr, out.ptr, n, xin.h, xin.w, xin.c,
                                                               xin.pix, out.pix, st))
                 else:
                     shift = int(round(math.log2(l.config["size"])))
+                    add = self._add_to_fuse(name)
+                    if add is not None:
+                        # Add([this up-sampling, a tensor that exists already]) (FPN's top-down path): the
+                        # kernel adds while it copies, and the up-sampled tensor itself is never stored
+                        other = self.acts[[i for i in g.layers[add].inbound if i != name][0]]
+                        out = self.new_out(add, l.out.h, l.out.w, l.out.c)
+                        L.check(lib.miseg_upsample_nearest_fwd(xin.ptr, other.ptr, out.ptr, n, xin.h, xin.w, xin.c,
+                                                               shift, xin.pix, other.pix, out.pix, st))
+                        self.acts[add] = out
+                        self.fused_adds.add(add)
+                        continue
                     L.check(lib.miseg_upsample_nearest_fwd(xin.ptr, None, out.ptr, n, xin.h, xin.w, xin.c,
                                                            shift, xin.pix, 0, out.pix, st))
                 self.acts[name] = out

@@ -57,7 +57,15 @@ def forward_errors(tr, weights):
         elif l.cls == "Add":
             # an input the trainer never stored is a convolution whose epilogue did the addition: its
             # (unrounded) result enters the reference instead
-            parts = [tr.acts[i].float().cpu() if i in tr.acts else conv_ref(i) for i in l.inbound]
+            def part(i):
+                if i in tr.acts:
+                    return tr.acts[i].float().cpu()
+                li = g.layers[i]
+                if li.cls == "UpSampling2D":      # fused as well: the kernel adds while it up-samples
+                    xf = tr.acts[li.inbound[0]].float().cpu().permute(0, 3, 1, 2)
+                    return F.interpolate(xf, scale_factor=li.config["size"], mode="nearest").permute(0, 2, 3, 1)
+                return conv_ref(i)
+            parts = [part(i) for i in l.inbound]
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(parts[0] + parts[1]))))
         elif l.cls == "Concatenate":
             ref = torch.cat([tr.acts[i].float().cpu() for i in l.inbound], dim=-1)
@@ -72,7 +80,7 @@ def forward_errors(tr, weights):
         elif l.cls == "AveragePooling2D":
             xf = tr.acts[l.inbound[0]].float().cpu().permute(0, 3, 1, 2)
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(F.avg_pool2d(xf, 2, 2).permute(0, 2, 3, 1)))))
-        elif l.cls == "UpSampling2D":
+        elif l.cls == "UpSampling2D" and name in tr.acts:
             xf = tr.acts[l.inbound[0]].float().cpu().permute(0, 3, 1, 2)
             if l.config["interpolation"] == "bilinear":
                 ref = F.interpolate(xf, scale_factor=2, mode="bilinear", align_corners=False)
