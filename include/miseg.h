@@ -150,6 +150,8 @@ typedef struct miseg_conv_desc {
                                  [n, oy >> s, ox >> s, co]: UpSampling2D(2^s, 'nearest') + Add in the
                                  epilogue, the top-down path of the FPN blocks (segmentation_models
                                  FPNBlock, reached from utils/model.py:200-211) */
+  int32_t out2_linear;        /* non-zero: the second output without its ReLU, out2 = v * scale2 + shift2 (a
+                                 biased copy of the result: the engine's split form of FPN's segm_stage2a) */
 } miseg_conv_desc;
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);

@@ -53,6 +53,7 @@ struct ConvParams {
   int ntiles;   // ceil(Cout / BN)
   int vec_ok;   // strides/pointers allow 16-byte epilogue accesses
   int tiles_y, tiles_x;  // halo kernel: output patches per image
+  int out2_linear;       // the second output without its ReLU: out2 = v * scale2 + shift2
   double* stats;         // optional per-channel sum / sum of squares of the stored bf16 output
   int stats_rep, stats_stride;
   int direct;            // generic kernels: finish large launches with the LDS-free epilogue
@@ -331,11 +332,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
           const float4 s1 = *reinterpret_cast<const float4*>(p.scale2 + cox + 4);
           const float4 t0 = *reinterpret_cast<const float4*>(p.shift2 + cox);
           const float4 t1 = *reinterpret_cast<const float4*>(p.shift2 + cox + 4);
+          const bool r2 = !p.out2_linear;
           *reinterpret_cast<uint4*>(p.out2 + o2_off) = make_uint4(
-              pack_h16x2_raw(h16_relu(v[0] * s0.x + t0.x), h16_relu(v[1] * s0.y + t0.y)),
-              pack_h16x2_raw(h16_relu(v[2] * s0.z + t0.z), h16_relu(v[3] * s0.w + t0.w)),
-              pack_h16x2_raw(h16_relu(v[4] * s1.x + t1.x), h16_relu(v[5] * s1.y + t1.y)),
-              pack_h16x2_raw(h16_relu(v[6] * s1.z + t1.z), h16_relu(v[7] * s1.w + t1.w)));
+              pack_h16x2_raw(h16_act(v[0] * s0.x + t0.x, r2), h16_act(v[1] * s0.y + t0.y, r2)),
+              pack_h16x2_raw(h16_act(v[2] * s0.z + t0.z, r2), h16_act(v[3] * s0.w + t0.w, r2)),
+              pack_h16x2_raw(h16_act(v[4] * s1.x + t1.x, r2), h16_act(v[5] * s1.y + t1.y, r2)),
+              pack_h16x2_raw(h16_act(v[6] * s1.z + t1.z, r2), h16_act(v[7] * s1.w + t1.w, r2)));
         }
         continue;
       }
@@ -371,7 +373,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
             reinterpret_cast<h16_t*>(p.out)[o_off + j] = f32_to_h16(w);
         }
         if (p.out2)
-          p.out2[o2_off + j] = f32_to_h16(fmaxf(v[j] * p.scale2[cox + j] + p.shift2[cox + j], 0.f));
+          p.out2[o2_off + j] = f32_to_h16(p.out2_linear ? v[j] * p.scale2[cox + j] + p.shift2[cox + j]
+                                                         : fmaxf(v[j] * p.scale2[cox + j] + p.shift2[cox + j], 0.f));
       }
     }
   });
@@ -533,11 +536,12 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
     if (d2) {
       const float* s = d2->s2 + 8 * q;
       const float* t = d2->t2 + 8 * q;
+      const bool r2 = !p.out2_linear;
       *reinterpret_cast<uint4*>(p.out2 + o2_off + d.c2[q]) = make_uint4(
-          pack_h16x2_raw(h16_relu(w[0] * s[0] + t[0]), h16_relu(w[1] * s[1] + t[1])),
-          pack_h16x2_raw(h16_relu(w[2] * s[2] + t[2]), h16_relu(w[3] * s[3] + t[3])),
-          pack_h16x2_raw(h16_relu(w[4] * s[4] + t[4]), h16_relu(w[5] * s[5] + t[5])),
-          pack_h16x2_raw(h16_relu(w[6] * s[6] + t[6]), h16_relu(w[7] * s[7] + t[7])));
+          pack_h16x2_raw(h16_act(w[0] * s[0] + t[0], r2), h16_act(w[1] * s[1] + t[1], r2)),
+          pack_h16x2_raw(h16_act(w[2] * s[2] + t[2], r2), h16_act(w[3] * s[3] + t[3], r2)),
+          pack_h16x2_raw(h16_act(w[4] * s[4] + t[4], r2), h16_act(w[5] * s[5] + t[5], r2)),
+          pack_h16x2_raw(h16_act(w[6] * s[6] + t[6], r2), h16_act(w[7] * s[7] + t[7], r2)));
     }
   }
 }

@@ -905,6 +905,7 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.dgrad_t = 0;
   p.res_after = d->res_after_act ? 1 : 0;
   p.res_shift = d->res_upsample_shift;
+  p.out2_linear = d->out2_linear ? 1 : 0;
   // one million output pixels: from there on the epilogue's HBM traffic, not its latency, is what a generic
   // launch waits for (measured on the full-resolution 1x1 layers of LinkNet and FPN: 1.1-2.2x faster)
   p.direct = (long long)d->N * d->Ho * d->Wo >= (1 << 20);

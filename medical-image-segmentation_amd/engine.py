@@ -196,7 +196,7 @@ class Engine:
     def conv(self, name, x, wptr, cout, k, stride=1, pad=0, out=None, out_dtype=L.DT_BF16,
              scale=None, shift=None, act=L.ACT_NONE, residual=None, out2=None, scale2=None,
              shift2=None, in_scale=None, in_shift=None, transposed=False, collapse=None,
-             temperature=1.0, tile_hint=0, build_only=False, res_after=False, res_shift=0):
+             temperature=1.0, tile_hint=0, build_only=False, res_after=False, res_shift=0, out2_linear=False):
         d = L.ConvDesc()
         cin = _ceil32(x.c)
         if x.c0 + cin > x.ctot:
@@ -247,6 +247,7 @@ class Engine:
         d.fmt = self.fmt
         d.res_after_act = 1 if res_after else 0
         d.res_upsample_shift = res_shift
+        d.out2_linear = 1 if out2_linear else 0
         pix_out = x.n * oh * ow
         nbytes = x.n * x.h * x.w * x.c * 2 + cout * d.KH * d.KW * cin * 2 * (4 if transposed else 1)
         if out is not None:
@@ -547,6 +548,49 @@ class Engine:
         nbytes = x.n * x.h * x.w * 128 * 2 + self.n * self.h * self.wd * c * 5
         self._add(self.lib.miseg_plan_add_fpn_head(self.plan, C.byref(d)), "final_upsampling+head_conv", nbytes)
 
+    @staticmethod
+    def _t2_weights(k):
+        """Phase weights [a, b][Cout][dy][dx][Cin] of `3x3 convolution (HWIO kernel k) after nearest x2
+        up-sampling` in the layout of the transpose-convolution kernels: the 3x3 taps that fall on the same
+        source pixel are summed (a = 0: rows y-1 <- ky 0, y <- ky 1 + ky 2; a = 1: y <- ky 0 + ky 1,
+        y+1 <- ky 2; columns alike)."""
+        rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+        ci, co = k.shape[2], k.shape[3]
+        wt = np.zeros((2, 2, co, 2, 2, ci), np.float32)
+        for a in range(2):
+            for b in range(2):
+                for dy in range(2):
+                    for dx in range(2):
+                        acc = np.zeros((ci, co), np.float32)
+                        for ky in rows[a][dy]:
+                            for kx in rows[b][dx]:
+                                acc += k[ky, kx]
+                        wt[a, b, :, dy, dx, :] = acc.T
+        return wt
+
+    def _fpn_segm2a_split(self, q3, skip):
+        """segm_stage2a on p2 = fpn_stage_p2_conv(skip) + bias + up2(p3) without p2: by linearity (zero padding
+        included) conv3x3(p2) = conv3x3(W_l skip) + conv3x3(up2(p3 + bias)), i.e. a 3x3 convolution of the
+        64-channel skip tensor with the composed kernel W_l W3[ky, kx] plus the phase convolution (see
+        _fpn_final_stage_split) of q3 = p3 + bias, which the p3 layer writes as its second output.  The
+        256-channel full-resolution tensor p2 and its 1x1 convolution never run."""
+        k3 = self.w["segm_stage2a_conv"]["kernel"].astype(np.float32)       # (3, 3, 256, 128)
+        kl = self.w["fpn_stage_p2_conv"]["kernel"].astype(np.float32)[0, 0]  # (Cskip, 256)
+        sc, sh = self.bn_fold("segm_stage2a_bn")
+        part = self.buf(2 * q3.h, 2 * q3.w, 128)
+        self.conv("segm_stage2a_coarse", q3, self.dev_h16(self._t2_weights(k3)), 128, 4, out=part, scale=sc,
+                  transposed=True)
+        cs = kl.shape[0]
+        wc = np.zeros((128, 3, 3, _ceil32(cs)), np.float32)
+        for ky in range(3):
+            for kx in range(3):
+                wc[:, ky, kx, :cs] = (kl.astype(np.float64) @ k3[ky, kx].astype(np.float64)).T
+        out = self.buf(skip.h, skip.w, 128)
+        self.conv("segm_stage2a", skip, self.dev_h16(wc), 128, 3, pad=1, out=out, scale=sc, shift=sh,
+                  act=L.ACT_RELU, residual=part)
+        self.taps["segm_stage2a_relu"] = out
+        return out
+
     def _fpn_final_stage_split(self, pyr):
         """final_stage (3x3, 512 -> 128, on [s2, up2(s3), up4(s4), up8(s5)]) without the up-sampled tensors.
         A 3x3 convolution of a nearest-x2 up-sampled tensor is, per output phase (row parity a, column
@@ -558,11 +602,11 @@ class Engine:
         quarter of the up-sampling traffic, and the 512-channel full-resolution buffer is gone.  The
         BatchNorm scale goes onto the T2 part in its own epilogue, which leaves (scale * conv + shift)
         + residual, then ReLU, for the epilogue of the 3x3 part."""
-        p2 = pyr[3]
-        s2 = self.buf(p2.h, p2.w, 128)
-        half = self.buf(p2.h // 2, p2.w // 2, 384)        # [s3, up2(s4), up4(s5)]
+        h2, w2 = 2 * pyr[2].h, 2 * pyr[2].w
+        s2 = self.buf(h2, w2, 128)
+        half = self.buf(h2 // 2, w2 // 2, 384)            # [s3, up2(s4), up4(s5)]
         for p, st, shift in zip(pyr, (5, 4, 3, 2), (3, 2, 1, 0)):
-            s = self.conv_bn_relu("segm_stage%da" % st, p, 3)
+            s = self._fpn_segm2a_split(*p) if isinstance(p, tuple) else self.conv_bn_relu("segm_stage%da" % st, p, 3)
             if shift == 0:
                 self.conv_bn_relu("segm_stage%db" % st, s, 3, out=s2)
             elif shift == 1:
@@ -575,24 +619,12 @@ class Engine:
                     "upsampling_stage%d" % st)
         k = self.w["final_stage_conv"]["kernel"].astype(np.float32)       # (3, 3, 512, 128)
         sc, sh = self.bn_fold("final_stage_bn")
-        # T2 weights [phase a, b][Cout][dy][dx][Cin = 384]
-        rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}      # phase -> 3x3 taps summed into dy = 0, 1
-        kc = k[:, :, 128:, :]
-        wt = np.zeros((2, 2, 128, 2, 2, 384), np.float32)
-        for a in range(2):
-            for b in range(2):
-                for dy in range(2):
-                    for dx in range(2):
-                        acc = np.zeros((384, 128), np.float32)
-                        for ky in rows[a][dy]:
-                            for kx in rows[b][dx]:
-                                acc += kc[ky, kx]
-                        wt[a, b, :, dy, dx, :] = acc.T
-        part = self.buf(p2.h, p2.w, 128)
+        wt = self._t2_weights(k[:, :, 128:, :])
+        part = self.buf(h2, w2, 128)
         self.conv("final_stage_coarse", half, self.dev_h16(wt), 128, 4, out=part, scale=sc, transposed=True)
         fine = np.zeros((128, 3, 3, 128), np.float32)
         fine[:] = k[:, :, :128, :].transpose(3, 0, 1, 2)
-        out = self.buf(p2.h, p2.w, 128)
+        out = self.buf(h2, w2, 128)
         self.conv("final_stage", s2, self.dev_h16(fine), 128, 3, pad=1, out=out, scale=sc, shift=sh,
                   act=L.ACT_RELU, residual=part)
         self.taps["final_stage_relu"] = out
@@ -682,17 +714,26 @@ class Engine:
                     x = y
                 lat = "fpn_stage_p%d_conv" % st
                 sk = skips[j]
+                if st == 2 and self.split_fpn_stage:
+                    # the finest level is consumed by segm_stage2a only: folded into it (_fpn_segm2a_split)
+                    pyr.append((q3, sk))
+                    continue
                 p = self.buf(sk.h, sk.w, 256)
-                # p = lateral(skip) + nearest_upsample_x2(x): the add in the convolution's epilogue
+                q3 = self.buf(sk.h, sk.w, 256) if st == 3 and self.split_fpn_stage else None
+                # p = lateral(skip) + nearest_upsample_x2(x): the add in the convolution's epilogue; the
+                # level above the finest one also leaves p + (bias of the finest level's lateral convolution)
                 self.conv(lat, sk, self.conv_weight(lat), 256, 1, out=p, shift=self.w[lat]["bias"],
-                          residual=x, res_shift=1)
+                          residual=x, res_shift=1, out2=q3,
+                          scale2=np.ones(256, np.float32) if q3 is not None else None,
+                          shift2=self.w["fpn_stage_p2_conv"]["bias"] if q3 is not None else None,
+                          out2_linear=q3 is not None)
                 self.taps["fpn_stage_p%d_add" % st] = p
                 pyr.append(p)
                 x = p
-            p2 = pyr[3]
             if self.split_fpn_stage:
                 x = self._fpn_final_stage_split(pyr)
             else:
+                p2 = pyr[3]
                 agg = self.buf(p2.h, p2.w, 512)        # [s2, s3, s4, s5]
                 for p, st, slot, shift in zip(pyr, (5, 4, 3, 2), (3, 2, 1, 0), (3, 2, 1, 0)):
                     s = self.conv_bn_relu("segm_stage%da" % st, p, 3)

@@ -42,6 +42,7 @@ class ConvDesc(C.Structure):
         ("tile_hint", C.c_int32),
         ("stats", C.c_void_p), ("stats_replicas", C.c_int32), ("stats_stride", C.c_int32),
         ("fmt", C.c_int32), ("res_after_act", C.c_int32), ("res_upsample_shift", C.c_int32),
+        ("out2_linear", C.c_int32),
     ]
 
 
