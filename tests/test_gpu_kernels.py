@@ -78,7 +78,7 @@ def dev_f32(a, dev):
 
 def run_conv(env, x, w_hwio, stride=1, pad=0, scale=None, shift=None, act=0, residual=None,
              res_f32=True, scale2=None, shift2=None, in_scale=None, in_shift=None, out_f32=False,
-             want_out=True, tile_hint=0, in_extra_c=0, out_extra_c=0, res_after=False, res_shift=0):
+             want_out=True, tile_hint=0, in_extra_c=0, out_extra_c=0, res_after=False, res_shift=0, out2_linear=False):
     """x: (N,H,W,Cin) fp32 (bf16-representable); returns (out, out2) as fp32 numpy."""
     L, lib, dev = env
     n, h, wd, cin = x.shape
@@ -131,6 +131,7 @@ def run_conv(env, x, w_hwio, stride=1, pad=0, scale=None, shift=None, act=0, res
     d.temperature = 1.0
     d.tile_hint = tile_hint
     d.res_after_act = 1 if res_after else 0
+    d.out2_linear = 1 if out2_linear else 0
     L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
     torch.cuda.synchronize()
     o = out[..., out_extra_c:].float().cpu().numpy() if want_out else None
@@ -257,6 +258,22 @@ def test_conv_epilogues(env):
     _, got2 = run_conv(env, x, wt, 1, 1, residual=resb, res_f32=False, scale2=s2, shift2=t2,
                        want_out=False)
     np.testing.assert_allclose(got2, np.maximum((base + resb) * s2 + t2, 0), rtol=1e-2, atol=1e-2)
+    # the second output without its ReLU (a biased copy of the result), through the LDS epilogue and, on a
+    # 128-channel 1x1 layer with an up-sampled residual (FPN's p3 layer), through the direct one
+    got, got2 = run_conv(env, x, wt, 1, 1, shift=sh, residual=resb, res_f32=False, scale2=s2, shift2=t2,
+                         out2_linear=True)
+    np.testing.assert_allclose(got, base + sh + resb, rtol=1e-2, atol=2e-2)
+    np.testing.assert_allclose(got2, (base + sh + resb) * s2 + t2, rtol=1e-2, atol=3e-2)
+    assert (got2 < 0).any()
+    x1 = bf16_round(rng.normal(0, 1, (1, 16, 24, 64)))
+    w1 = bf16_round(rng.normal(0, 0.1, (1, 1, 64, 128)))
+    r1 = bf16_round(rng.normal(0, 1, (1, 8, 12, 128)))
+    b2 = rng.normal(0, 0.5, 128).astype(np.float32)
+    got, got2 = run_conv(env, x1, w1, 1, 0, residual=r1, res_f32=False, res_shift=1, scale2=np.ones(128, np.float32),
+                         shift2=b2, out2_linear=True)
+    want = ref_conv(x1, w1, 1, 0) + np.repeat(np.repeat(r1, 2, 1), 2, 2)
+    np.testing.assert_allclose(got, want, rtol=1e-2, atol=2e-2)
+    np.testing.assert_allclose(got2, want + b2, rtol=1e-2, atol=3e-2)
 
 
 @pytest.mark.parametrize("shape", [(3, 250, 400, 32, 32), (1, 37, 70, 32, 24), (2, 8, 32, 32, 8), (5, 129, 257, 32, 16)])
