@@ -257,6 +257,21 @@ typedef struct miseg_fpn_head_desc {
 int miseg_fpn_head_fwd(const miseg_fpn_head_desc* d, void* stream);
 
 /*
+ * The same head with its channel contraction done at half resolution first.  UpSampling2D(2, 'bilinear') +
+ * Conv2D(3x3, 128 -> classes) (segmentation_models build_fpn: final_upsampling, head_conv; reached from
+ * /root/reference utils/model.py:200-211) is linear in its input, so the nine taps' contractions
+ * y[tap * classes + c] = W[tap][:, c] . x can run as ONE 1x1 convolution with 9 * classes output channels
+ * (miseg_conv2d_fwd, fp32 output) on the half-resolution tensor; this entry point finishes the layer: per
+ * output pixel, for every tap position inside the image (the convolution's zero padding), the bilinear
+ * sample (half-pixel centres, clamped) of that tap's values, their sum + bias, softmax (with temperature) or
+ * sigmoid, and the collapse_probabilities mask (utils/utils.py:50-68).
+ *   y: fp32 [N][h][w][y_pix_stride]; probs: fp32 [N][2h][2w][classes]; collapse_out: u8, same extents, or NULL.
+ */
+int miseg_head_gather_fwd(const float* y, const float* bias, float* probs, void* collapse_out, int32_t N,
+                          int32_t h, int32_t w, int32_t classes, int32_t y_pix_stride, int32_t act,
+                          float temperature, int32_t collapse_value, void* stream);
+
+/*
  * Input contract of the encoders: fp32 NHWC image with 3 channels ->
  * bf16 [N][H+6][W+8][4] with the image at rows 3.., columns 3.., channel 3 and
  * the border zero; value = x*scale[c] + shift[c] (ResNet `bn_data`, a
@@ -605,6 +620,9 @@ int miseg_plan_add_maxpool2x2(miseg_plan* p, const void* in, void* out, int32_t 
                               int32_t W, int32_t C, int32_t in_pix_stride,
                               int32_t out_pix_stride);
 int miseg_plan_add_im2col3x3(miseg_plan* p, const float* in, void* out, int32_t N, int32_t H, int32_t W);
+int miseg_plan_add_head_gather(miseg_plan* p, const float* y, const float* bias, float* probs, void* collapse_out,
+                               int32_t N, int32_t h, int32_t w, int32_t classes, int32_t y_pix_stride,
+                               int32_t act, float temperature, int32_t collapse_value);
 int miseg_plan_add_upsample_nearest(miseg_plan* p, const void* in, const void* addend, void* out,
                                     int32_t N, int32_t H, int32_t W, int32_t C, int32_t shift,
                                     int32_t in_pix_stride, int32_t add_pix_stride,

@@ -19,6 +19,8 @@ void set_error(const char* fmt, ...) {
 
 #include "inference_decls.inc"
 int launch_collapse_u8(const float*, uint8_t*, long long, int, int, hipStream_t);
+int launch_head_gather(const float*, const float*, float*, uint8_t*, int, int, int, int, int, int, float, int,
+                       hipStream_t);
 int launch_loss_sums(const float*, const float*, double*, long long, int, hipStream_t);
 int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream);
 int launch_bn_finalize(const double*, int, int, long long, int, const float*, const float*, float*, float*,
@@ -69,7 +71,7 @@ namespace miseg_f16 {
 namespace miseg {
 
 enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD, OP_DENSE, OP_LTAIL, OP_FPNHEAD,
-              OP_MAXPOOL2, OP_IM2COL };
+              OP_MAXPOOL2, OP_IM2COL, OP_HEADGATHER };
 
 struct Op {
   OpKind kind;
@@ -84,6 +86,8 @@ struct Op {
   const float* shift;
   long long pixels;
   int N, H, W, C, shift_bits, ips, aps, ops;
+  int act, cval;        // OP_HEADGATHER
+  float temperature;
 };
 
 static int run_op_f16(const Op& o, hipStream_t s) {
@@ -100,6 +104,9 @@ static int run_op_f16(const Op& o, hipStream_t s) {
     case OP_AVGPOOL: return F::launch_avgpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
     case OP_MAXPOOL2: return F::launch_maxpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
     case OP_IM2COL: return F::launch_im2col3x3((const float*)o.in, o.out, o.N, o.H, o.W, 9, s);
+    case OP_HEADGATHER:
+      return ::miseg::launch_head_gather((const float*)o.in, o.scale, (float*)o.out, (uint8_t*)const_cast<void*>(o.in2), o.N,
+                                         o.H, o.W, o.C, o.ips, o.act, o.temperature, o.cval, s);
     case OP_UPNEAR:
       return F::launch_upsample_nearest(o.in, o.in2, o.out, o.N, o.H, o.W, o.C, o.shift_bits, o.ips,
                                         o.aps, o.ops, s);
@@ -125,6 +132,9 @@ static int run_op(const Op& o, hipStream_t s, int fmt) {
     case OP_AVGPOOL: return launch_avgpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
     case OP_MAXPOOL2: return launch_maxpool2x2(o.in, o.out, o.N, o.H, o.W, o.C, o.ips, o.ops, s);
     case OP_IM2COL: return launch_im2col3x3((const float*)o.in, o.out, o.N, o.H, o.W, 9, s);
+    case OP_HEADGATHER:
+      return ::miseg::launch_head_gather((const float*)o.in, o.scale, (float*)o.out, (uint8_t*)const_cast<void*>(o.in2), o.N,
+                                         o.H, o.W, o.C, o.ips, o.act, o.temperature, o.cval, s);
     case OP_UPNEAR:
       return launch_upsample_nearest(o.in, o.in2, o.out, o.N, o.H, o.W, o.C, o.shift_bits, o.ips,
                                      o.aps, o.ops, s);
@@ -545,6 +555,25 @@ int miseg_plan_add_maxpool2x2(miseg_plan* p, const void* in, void* out, int32_t 
   return MISEG_OK;
 }
 
+int miseg_head_gather_fwd(const float* y, const float* bias, float* probs, void* collapse_out, int32_t N,
+                          int32_t h, int32_t w, int32_t classes, int32_t y_pix_stride, int32_t act,
+                          float temperature, int32_t collapse_value, void* stream) {
+  return launch_head_gather(y, bias, probs, (uint8_t*)collapse_out, N, h, w, classes, y_pix_stride, act, temperature,
+                            collapse_value, (hipStream_t)stream);
+}
+
+int miseg_plan_add_head_gather(miseg_plan* p, const float* y, const float* bias, float* probs, void* collapse_out,
+                               int32_t N, int32_t h, int32_t w, int32_t classes, int32_t y_pix_stride,
+                               int32_t act, float temperature, int32_t collapse_value) {
+  MISEG_CHECK_ARG(p, "plan: null plan");
+  Op o{};
+  o.kind = OP_HEADGATHER; o.in = y; o.scale = bias; o.out = probs; o.in2 = collapse_out;
+  o.N = N; o.H = h; o.W = w; o.C = classes; o.ips = y_pix_stride;
+  o.act = act; o.temperature = temperature; o.cval = collapse_value;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
 int miseg_plan_add_im2col3x3(miseg_plan* p, const float* in, void* out, int32_t N, int32_t H, int32_t W) {
   MISEG_CHECK_ARG(p, "plan: null plan");
   Op o{};
@@ -643,7 +672,7 @@ int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t bufl
   static const char* names[] = {"", "prep_input_kernel", "maxpool3x3s2_kernel", "avgpool2x2_kernel",
                                 "upsample_nearest_kernel", "upsample_bilinear2x_kernel",
                                 "scale_shift_relu_kernel", "", "", "", "", "maxpool2x2_kernel",
-                                "im2col3x3_kernel"};
+                                "im2col3x3_kernel", "head_gather_kernel"};
   if (o.kind == OP_CONV)
     conv_kernel_name(&o.conv, buf, buflen);
   else if (o.kind == OP_CONV_HEAD)

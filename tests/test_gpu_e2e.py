@@ -169,6 +169,8 @@ def test_layerwise_forms_of_fused_kernels():
     check_engine("densenet121", "Linknet", (64, 96), 1, 3, fuse_tail=False, fuse_dense=False)
     check_engine("resnet18", "U-Net", (64, 96), 2, 3, fuse_tail=False)
     check_engine("resnet18", "FPN", (96, 160), 1, 3, fuse_tail=False)
+    check_engine("resnet18", "FPN", (96, 160), 2, 3, head_gather=False)      # the full-resolution fused head kernel
+    check_engine("resnet18", "FPN", (64, 96), 1, 1, head_gather=False)
 
 
 def check_engine(enc, dec, hw, n, classes, **engine_options):

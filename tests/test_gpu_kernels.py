@@ -510,6 +510,45 @@ def test_conv_head_softmax_collapse(env, classes, act):
     np.testing.assert_array_equal(mask.cpu().numpy(), want_mask)
 
 
+@pytest.mark.parametrize("classes,act,hw", [(3, 2, (10, 12)), (3, 2, (9, 35)), (4, 2, (17, 33)), (1, 3, (8, 32)),
+                                            (2, 2, (3, 70))])
+def test_head_gather(env, classes, act, hw):
+    """final_upsampling (bilinear x2) + 3x3 head from the nine taps' channel contractions done at half
+    resolution: logits of the plain order of operations (oracle), ragged tiles included."""
+    from oracle import ops_np, post
+    L, lib, dev = env
+    rng = np.random.default_rng(17)
+    n, (h, w), cin = 2, hw, 16
+    x = rng.normal(0, 1, (n, h, w, cin)).astype(np.float32)
+    k = rng.normal(0, 0.3, (3, 3, cin, classes)).astype(np.float32)
+    bias = rng.normal(0, 0.1, classes).astype(np.float32)
+    temp = 0.7
+    logits = ops_np.conv2d(ops_np.upsample_bilinear2x(x), k, pad=1, bias=bias)
+    want = ops_np.softmax(logits, temp) if act == 2 else ops_np.sigmoid(logits)
+    ypix = (9 * classes + 31) // 32 * 32
+    y = np.full((n, h, w, ypix), 7.0, np.float32)             # the padding channels are never read
+    y[..., :9 * classes] = np.einsum("nhwc,tco->nhwto", x.astype(np.float64),
+                                     k.reshape(9, cin, classes).astype(np.float64)).reshape(n, h, w, 9 * classes)
+    yd, bd = dev_f32(y, dev), dev_f32(bias, dev)
+    out = torch.zeros((n, 2 * h, 2 * w, classes), dtype=torch.float32, device=dev)
+    mask = torch.zeros((n, 2 * h, 2 * w, classes), dtype=torch.uint8, device=dev)
+    L.check(lib.miseg_head_gather_fwd(yd.data_ptr(), bd.data_ptr(), out.data_ptr(), mask.data_ptr(),
+                                             n, h, w, classes, ypix, act, temp, 127, None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+    want_mask = np.stack([post.collapse_probabilities(got[i], 127) for i in range(n)])
+    np.testing.assert_array_equal(mask.cpu().numpy(), want_mask)
+    # no mask asked for: the probabilities alone
+    out2 = torch.zeros_like(out)
+    L.check(lib.miseg_head_gather_fwd(yd.data_ptr(), bd.data_ptr(), out2.data_ptr(), None,
+                                             n, h, w, classes, ypix, act, temp, 127, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+    assert lib.miseg_head_gather_fwd(yd.data_ptr(), bd.data_ptr(), out2.data_ptr(), None,
+                                            n, h, w, 5, ypix, act, temp, 127, None) != 0
+
+
 def test_prep_input_and_stem(env):
     """bn_data + ZeroPadding2D(3) + 7x7/2 stem conv via the channel-padded 7x1 form."""
     from oracle import ops_np
