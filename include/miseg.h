@@ -266,10 +266,23 @@ int miseg_fpn_head_fwd(const miseg_fpn_head_desc* d, void* stream);
  * sample (half-pixel centres, clamped) of that tap's values, their sum + bias, softmax (with temperature) or
  * sigmoid, and the collapse_probabilities mask (utils/utils.py:50-68).
  *   y: fp32 [N][h][w][y_pix_stride]; probs: fp32 [N][2h][2w][classes]; collapse_out: u8, same extents, or NULL.
+ *   class_major != 0: y's channels are ordered c * 9 + tap instead, i.e. the 1x1 convolution used the rows of the
+ *   head's [class][3][3][cin] weight tensor as they lie (what the training path does: no re-packing per step).
  */
 int miseg_head_gather_fwd(const float* y, const float* bias, float* probs, void* collapse_out, int32_t N,
                           int32_t h, int32_t w, int32_t classes, int32_t y_pix_stride, int32_t act,
-                          float temperature, int32_t collapse_value, void* stream);
+                          float temperature, int32_t collapse_value, int32_t class_major, void* stream);
+
+/*
+ * Backward of that step (the adjoint of sampling + tap summation), for training the same head without the
+ * full-resolution 128-channel tensor: dz = d loss / d logits (bf16 [N][2h][2w][dz_pix_stride], first `classes`
+ * channels) -> dy = d loss / d y (bf16 [N][h][w][dy_pix_stride], channel c * 9 + tap, zeros from 9 * classes on).
+ * The 1x1 convolution's own data and weight gradients (miseg_conv2d_fwd with the transposed weights,
+ * miseg_conv2d_wgrad) then run at half resolution.  Replaces the backward of UpSampling2D + Conv2D that
+ * Keras derives inside model.fit (/root/reference utils/model.py:200-211, model_train.py:284-329).
+ */
+int miseg_head_gather_bwd(const void* dz, int32_t dz_pix_stride, void* dy, int32_t N, int32_t h, int32_t w,
+                          int32_t classes, int32_t dy_pix_stride, void* stream);
 
 /*
  * Input contract of the encoders: fp32 NHWC image with 3 channels ->

@@ -19,8 +19,9 @@ void set_error(const char* fmt, ...) {
 
 #include "inference_decls.inc"
 int launch_collapse_u8(const float*, uint8_t*, long long, int, int, hipStream_t);
-int launch_head_gather(const float*, const float*, float*, uint8_t*, int, int, int, int, int, int, float, int,
+int launch_head_gather(const float*, const float*, float*, uint8_t*, int, int, int, int, int, int, float, int, int,
                        hipStream_t);
+int launch_head_gather_bwd(const void*, int, void*, int, int, int, int, int, hipStream_t);
 int launch_loss_sums(const float*, const float*, double*, long long, int, hipStream_t);
 int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream);
 int launch_bn_finalize(const double*, int, int, long long, int, const float*, const float*, float*, float*,
@@ -106,7 +107,7 @@ static int run_op_f16(const Op& o, hipStream_t s) {
     case OP_IM2COL: return F::launch_im2col3x3((const float*)o.in, o.out, o.N, o.H, o.W, 9, s);
     case OP_HEADGATHER:
       return ::miseg::launch_head_gather((const float*)o.in, o.scale, (float*)o.out, (uint8_t*)const_cast<void*>(o.in2), o.N,
-                                         o.H, o.W, o.C, o.ips, o.act, o.temperature, o.cval, s);
+                                         o.H, o.W, o.C, o.ips, o.act, o.temperature, o.cval, 0, s);
     case OP_UPNEAR:
       return F::launch_upsample_nearest(o.in, o.in2, o.out, o.N, o.H, o.W, o.C, o.shift_bits, o.ips,
                                         o.aps, o.ops, s);
@@ -134,7 +135,7 @@ static int run_op(const Op& o, hipStream_t s, int fmt) {
     case OP_IM2COL: return launch_im2col3x3((const float*)o.in, o.out, o.N, o.H, o.W, 9, s);
     case OP_HEADGATHER:
       return ::miseg::launch_head_gather((const float*)o.in, o.scale, (float*)o.out, (uint8_t*)const_cast<void*>(o.in2), o.N,
-                                         o.H, o.W, o.C, o.ips, o.act, o.temperature, o.cval, s);
+                                         o.H, o.W, o.C, o.ips, o.act, o.temperature, o.cval, 0, s);
     case OP_UPNEAR:
       return launch_upsample_nearest(o.in, o.in2, o.out, o.N, o.H, o.W, o.C, o.shift_bits, o.ips,
                                      o.aps, o.ops, s);
@@ -557,9 +558,14 @@ int miseg_plan_add_maxpool2x2(miseg_plan* p, const void* in, void* out, int32_t 
 
 int miseg_head_gather_fwd(const float* y, const float* bias, float* probs, void* collapse_out, int32_t N,
                           int32_t h, int32_t w, int32_t classes, int32_t y_pix_stride, int32_t act,
-                          float temperature, int32_t collapse_value, void* stream) {
+                          float temperature, int32_t collapse_value, int32_t class_major, void* stream) {
   return launch_head_gather(y, bias, probs, (uint8_t*)collapse_out, N, h, w, classes, y_pix_stride, act, temperature,
-                            collapse_value, (hipStream_t)stream);
+                            collapse_value, class_major, (hipStream_t)stream);
+}
+
+int miseg_head_gather_bwd(const void* dz, int32_t dz_pix_stride, void* dy, int32_t N, int32_t h, int32_t w,
+                          int32_t classes, int32_t dy_pix_stride, void* stream) {
+  return launch_head_gather_bwd(dz, dz_pix_stride, dy, N, h, w, classes, dy_pix_stride, (hipStream_t)stream);
 }
 
 int miseg_plan_add_head_gather(miseg_plan* p, const float* y, const float* bias, float* probs, void* collapse_out,

@@ -9,7 +9,8 @@
 
 namespace miseg {
 
-// y: fp32 [N][h][w][ypix], channel tap * C + c (tap = ky * 3 + kx).  Output extents 2h x 2w.
+// y: fp32 [N][h][w][ypix], channel tap * C + c (tap = ky * 3 + kx), or c * 9 + tap when CM (class-major:
+// the rows of a [class][3][3][cin] weight tensor taken as they lie).  Output extents 2h x 2w.
 // Bilinear source of destination index q (tf.image.resize, half-pixel centres): s = (q + 0.5) / 2 - 0.5
 // clamped to [0, n - 1]; rows floor(s) and min(floor(s) + 1, n - 1) with weights 1 - f, f.
 //
@@ -27,7 +28,7 @@ namespace miseg {
 // different banks.
 constexpr int HG_TW = 32, HG_TH = 8;
 
-template <int C>
+template <int C, bool CM>
 __global__ __launch_bounds__(256) void head_gather_kernel(const float* __restrict__ y, const float* __restrict__ bias,
                                                           float* __restrict__ probs, uint8_t* __restrict__ collapse,
                                                           int N, int h, int w, int ypix, int act, float inv_temperature,
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void head_gather_kernel(const float* __restric
             for (int bb = 0; bb < 2; ++bb) {
               const float wgt = wyc[a + ty] * wxc[bb + tx];
 #pragma unroll
-              for (int c = 0; c < C; ++c) v[a][bb][c] += wgt * t[(ty * 3 + tx) * C + c];
+              for (int c = 0; c < C; ++c) v[a][bb][c] += wgt * t[CM ? c * 9 + ty * 3 + tx : (ty * 3 + tx) * C + c];
             }
     }
 #pragma unroll
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(256) void head_gather_kernel(const float* __restric
 }
 
 int launch_head_gather(const float* y, const float* bias, float* probs, uint8_t* collapse, int N, int h, int w,
-                       int classes, int ypix, int act, float temperature, int collapse_value, hipStream_t s) {
+                       int classes, int ypix, int act, float temperature, int collapse_value, int class_major,
+                       hipStream_t s) {
   MISEG_CHECK_ARG(y && probs && N > 0 && h > 0 && w > 0, "head_gather: bad argument");
   MISEG_CHECK_ARG(classes >= 1 && classes <= 4 && ypix >= (9 * classes + 3) / 4 * 4 && (ypix & 3) == 0 &&
                       ((uintptr_t)y & 15) == 0,
@@ -175,9 +177,13 @@ int launch_head_gather(const float* y, const float* bias, float* probs, uint8_t*
   const long long g = (long long)N * tiles_x * tiles_y;
   MISEG_CHECK_ARG(g < (1ll << 31), "head_gather: too many tiles for one launch");
   const float it = 1.f / temperature;
-#define MISEG_HG(Cn)                                                                                              \
-  hipLaunchKernelGGL(head_gather_kernel<Cn>, dim3((int)g), dim3(256), 0, s, y, bias, probs, collapse, N, h, w, ypix, \
-                     act, it, collapse_value, tiles_x, tiles_y)
+#define MISEG_HG(Cn)                                                                                                \
+  if (class_major)                                                                                                  \
+    hipLaunchKernelGGL((head_gather_kernel<Cn, true>), dim3((int)g), dim3(256), 0, s, y, bias, probs, collapse, N, \
+                       h, w, ypix, act, it, collapse_value, tiles_x, tiles_y);                                     \
+  else                                                                                                              \
+    hipLaunchKernelGGL((head_gather_kernel<Cn, false>), dim3((int)g), dim3(256), 0, s, y, bias, probs, collapse, N, \
+                       h, w, ypix, act, it, collapse_value, tiles_x, tiles_y)
   switch (classes) {
     case 1: MISEG_HG(1); break;
     case 2: MISEG_HG(2); break;
@@ -185,6 +191,128 @@ int launch_head_gather(const float* y, const float* bias, float* probs, uint8_t*
     default: MISEG_HG(4); break;
   }
 #undef MISEG_HG
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
+// The adjoint of the gather above, for training: dz = d loss / d logits (bf16 [N][2h][2w][dzs], the first C
+// channels) -> dy = d loss / d y (bf16 [N][h][w][ypix], channel c * 9 + tap, zeros from 9 * C on).
+//   dy[Y][X][c][ky][kx] = sum over the tap positions q = (qy, qx) inside the image whose bilinear sample
+//   uses cell (Y, X), of its weight there times dz at the output pixel (qy - ky + 1, qx - kx + 1), when that
+//   pixel exists.
+// The rows that sample cell row Y are qy = 2Y-1 .. 2Y+2, so the output pixels involved are the 6 x 6 patch
+// from (2Y-2, 2X-2); one thread per cell walks the patch row by row: R[ky][col] += wy[r + ky - 2] * P[r][col],
+// then dy[ky][kx] = sum_qj wx[qj] * R[ky][qj - kx + 2].
+template <int C>
+__global__ __launch_bounds__(256) void head_gather_bwd_kernel(const bf16_t* __restrict__ dz, bf16_t* __restrict__ dy,
+                                                              int N, int h, int w, int dzs, int ypix) {
+  const int H = 2 * h, W = 2 * w;
+  const long long total = (long long)N * h * w;
+  constexpr int NO = (9 * C + 7) / 8 * 8;
+  const bool vec = (dzs & 3) == 0 && ((uintptr_t)dz & 7) == 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int X = (int)(i % w);
+    const long long r_ = i / w;
+    const int Y = (int)(r_ % h);
+    const int n = (int)(r_ / h);
+    // weight of cell row Y (column X) in the bilinear sample at row 2Y-1+qi (column 2X-1+qi); zero for a
+    // position outside the image
+    float wy[4], wx[4];
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) {
+      const int qy = 2 * Y - 1 + qi, qx = 2 * X - 1 + qi;
+      const float sy = fminf(fmaxf(qy * 0.5f - 0.25f, 0.f), (float)(h - 1));
+      const float sx = fminf(fmaxf(qx * 0.5f - 0.25f, 0.f), (float)(w - 1));
+      const int y0 = (int)sy, x0 = (int)sx;
+      const float fy = sy - (float)y0, fx = sx - (float)x0;
+      const float cy = (y0 == Y ? 1.f - fy : 0.f) + (min(y0 + 1, h - 1) == Y ? fy : 0.f);
+      const float cx = (x0 == X ? 1.f - fx : 0.f) + (min(x0 + 1, w - 1) == X ? fx : 0.f);
+      wy[qi] = (unsigned)qy < (unsigned)H ? cy : 0.f;
+      wx[qi] = (unsigned)qx < (unsigned)W ? cx : 0.f;
+    }
+    float R[3][6][C];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int col = 0; col < 6; ++col)
+#pragma unroll
+        for (int c = 0; c < C; ++c) R[ky][col][c] = 0.f;
+    const bf16_t* dzn = dz + (long long)n * H * W * dzs;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int oy = 2 * Y - 2 + r;
+      if ((unsigned)oy >= (unsigned)H) continue;
+      float P[6][C];
+#pragma unroll
+      for (int col = 0; col < 6; ++col) {
+        const int ox = 2 * X - 2 + col;
+        const bool ok = (unsigned)ox < (unsigned)W;
+        const bf16_t* src = dzn + ((long long)oy * W + (ok ? ox : 0)) * dzs;
+        if (vec) {
+          // the pixel's first four channels in one 8-byte load
+          const uint2 v = *reinterpret_cast<const uint2*>(src);
+          const float f[4] = {bf16lo_to_f32(v.x), bf16hi_to_f32(v.x), bf16lo_to_f32(v.y), bf16hi_to_f32(v.y)};
+#pragma unroll
+          for (int c = 0; c < C; ++c) P[col][c] = ok ? f[c] : 0.f;
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) P[col][c] = ok ? bf16_to_f32(src[c]) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int qi = r + ky - 2;            // the tap position's row is 2Y-1+qi
+        if (qi < 0 || qi > 3) continue;
+#pragma unroll
+        for (int col = 0; col < 6; ++col)
+#pragma unroll
+          for (int c = 0; c < C; ++c) R[ky][col][c] += wy[qi] * P[col][c];
+      }
+    }
+    float o[NO];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int qj = 0; qj < 4; ++qj)
+#pragma unroll
+          for (int c = 0; c < C; ++c) o[c * 9 + ky * 3 + kx] += wx[qj] * R[ky][qj - kx + 2][c];
+    uint4* dst = reinterpret_cast<uint4*>(dy + i * ypix);
+#pragma unroll
+    for (int k = 0; k < NO / 8; ++k) {
+      float o8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o8[j] = o[8 * k + j];
+      dst[k] = make_uint4(pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]),
+                          pack_bf16x2(o8[6], o8[7]));
+    }
+    for (int k = NO / 8; k < (ypix >> 3); ++k) dst[k] = make_uint4(0, 0, 0, 0);
+  }
+}
+
+int launch_head_gather_bwd(const void* dz, int dzs, void* dy, int N, int h, int w, int classes, int ypix,
+                           hipStream_t s) {
+  MISEG_CHECK_ARG(dz && dy && N > 0 && h > 0 && w > 0, "head_gather_bwd: bad argument");
+  MISEG_CHECK_ARG(classes >= 1 && classes <= 4 && dzs >= classes && (ypix & 7) == 0 &&
+                      ypix >= (9 * classes + 7) / 8 * 8 && ((uintptr_t)dy & 15) == 0,
+                  "head_gather_bwd: 1..4 classes, dy pixels of a multiple of 8 channels >= 9 * classes, 16-byte aligned");
+  const long long total = (long long)N * h * w;
+  long long g = (total + 255) / 256;
+  if (g > 256 * 64) g = 256 * 64;
+#define MISEG_HGB(Cn)                                                                                         \
+  hipLaunchKernelGGL(head_gather_bwd_kernel<Cn>, dim3((int)g), dim3(256), 0, s, (const bf16_t*)dz, (bf16_t*)dy, N, \
+                     h, w, dzs, ypix)
+  switch (classes) {
+    case 1: MISEG_HGB(1); break;
+    case 2: MISEG_HGB(2); break;
+    case 3: MISEG_HGB(3); break;
+    default: MISEG_HGB(4); break;
+  }
+#undef MISEG_HGB
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
 }

@@ -171,7 +171,9 @@ SIGNATURES = {
     "miseg_plan_add_im2col3x3": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32]),
     "miseg_plan_add_head_gather": (C.c_int, [_VP, _VP, _FP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, C.c_float,
                                              _I32]),
-    "miseg_head_gather_fwd": (C.c_int, [_VP, _FP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, C.c_float, _I32, _VP]),
+    "miseg_head_gather_fwd": (C.c_int, [_VP, _FP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, C.c_float, _I32, _I32,
+                                        _VP]),
+    "miseg_head_gather_bwd": (C.c_int, [_VP, _I32, _VP, _I32, _I32, _I32, _I32, _I32, _VP]),
     "miseg_plan_add_upsample_nearest": (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "miseg_plan_add_upsample_bilinear2x": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32]),
     "miseg_plan_add_scale_shift_relu": (C.c_int, [_VP, _VP, _VP, _FP, _FP, _I64, _I32, _I32, _I32]),

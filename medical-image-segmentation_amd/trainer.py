@@ -142,6 +142,27 @@ class Trainer:
                 if i not in self.place and g.layers[i].cls not in ("InputLayer", "ZeroPadding2D"):
                     self.place[i] = (l.name, c0)
                 c0 += c
+        self.head_up = self._fused_head_source()
+
+    def _fused_head_source(self):
+        """Name of the UpSampling2D(2, 'bilinear') whose only consumer is the 3x3 head convolution (the FPN
+        decoder's final_upsampling + head_conv), else None.  Both layers are linear, so the head's nine
+        channel contractions run at half resolution as one 1x1 convolution with 9 * classes outputs and a
+        gather kernel samples and sums them; the backward is the adjoint gather followed by the 1x1
+        convolution's gradients.  Neither the up-sampled tensor nor its gradient exists."""
+        g = self.g
+        head = g.layers[g.logits_layer]
+        if os.environ.get("MISEG_NO_FUSED_HEAD") or head.cls != "Conv2D" or head.name in self.frozen:
+            return None
+        cfg = head.config
+        if cfg["kernel_size"] != 3 or cfg["strides"] != 1 or cfg["padding"] != "same" or head.out.c > 3 or \
+                cfg.get("activation") == "relu":
+            return None
+        up = g.layers[head.inbound[0]]
+        if up.cls != "UpSampling2D" or up.config["interpolation"] != "bilinear" or up.config["size"] != 2 or \
+                self.consumers[up.name] != [head.name]:
+            return None
+        return up.name if g.layers[up.inbound[0]].out.c % 32 == 0 else None
 
     def _src(self, name):
         """Skip ZeroPadding2D: returns (producer layer name, accumulated padding)."""
@@ -618,8 +639,23 @@ class Trainer:
                     L.check(lib.miseg_im2col3x3_fwd(self.x_in.data_ptr(), t.data_ptr(), n, self.H, self.W, 1,
                                                     L.FMT_BF16, st))
                     self.acts[src] = Act(t, 3)
-                xin = self.acts[src]
                 relu = l.config.get("activation") == "relu"
+                if name == g.logits_layer and self.head_up is not None:
+                    # rows c * 9 + tap of the head's [class][3][3][cin] weights as a 1x1 convolution at half
+                    # resolution (fp32 result), then sampling, tap sum, bias and activation in one kernel
+                    xin = self.acts[g.layers[self.head_up].inbound[0]]
+                    y = torch.empty((n, xin.h, xin.w, 32), dtype=torch.float32, device=self.dev)
+                    self.conv(xin, self.wptr(name), 32, 1, 1, 1, 1, 0, 0, None, xin.h, xin.w, probs=y)
+                    probs = torch.empty((n, l.out.h, l.out.w, co), dtype=torch.float32, device=self.dev)
+                    act = L.ACT_SIGMOID if g.activation == "sigmoid" else L.ACT_SOFTMAX
+                    self.lib.note("head_gather_kernel", 0, y.numel() * 4 + probs.numel() * 4)
+                    L.check(lib.miseg_head_gather_fwd(y.data_ptr(), bias, probs.data_ptr(), None, n, xin.h, xin.w,
+                                                      co, 32, act, g.temperature if g.temperature else 1.0, 0, 1,
+                                                      st))
+                    self.probs = probs
+                    self.saved[name] = (xin, pad)
+                    continue
+                xin = self.acts[src]
                 if name == g.logits_layer:
                     probs = torch.empty((n, l.out.h, l.out.w, co), dtype=torch.float32, device=self.dev)
                     act = L.ACT_SIGMOID if g.activation == "sigmoid" else L.ACT_SOFTMAX
@@ -737,6 +773,8 @@ class Trainer:
                 L.check(lib.miseg_avgpool2x2_fwd(xin.ptr, out.ptr, n, xin.h, xin.w, xin.c, xin.pix, out.pix, st))
                 self.acts[name] = out
             elif cls == "UpSampling2D":
+                if name == self.head_up:
+                    continue                       # sampled inside the head's gather kernel
                 xin = self.acts[l.inbound[0]]
                 out = self.new_out(name, l.out.h, l.out.w, l.out.c) if self._add_to_fuse(name) is None or \
                     l.config["interpolation"] == "bilinear" else None
@@ -877,10 +915,11 @@ class Trainer:
         self.accum_log, self.accum_final = {}, {}
         c = self.classes
         head = g.layers[g.logits_layer]
-        dz = torch.empty((n, self.H, self.W, 32), dtype=torch.bfloat16, device=self.dev)   # the kernel zero-pads
+        dzc = 8 if self.head_up is not None else 32          # the fused head reads `classes` channels per pixel
+        dz = torch.empty((n, self.H, self.W, dzc), dtype=torch.bfloat16, device=self.dev)   # the kernel zero-pads
         temp = g.temperature if g.temperature else 1.0
         L.check(lib.miseg_loss_grad_ex(self.gt.data_ptr(), self.probs.data_ptr(), self.loss_sums.data_ptr(),
-                                       dz.data_ptr(), n * self.H * self.W, c, 32, loss_scale, temp,
+                                       dz.data_ptr(), n * self.H * self.W, c, dzc, loss_scale, temp,
                                        self.loss_flags, self.focal_alpha, self.focal_gamma, st))
         grads[head.name] = Act(dz, c)
         if self.buckets is not None:
@@ -908,7 +947,9 @@ class Trainer:
             dy = grads.pop(name)
             if self.grad_log is not None:
                 self.accum_final[name] = dy
-            if cls == "Conv2D":
+            if cls == "Conv2D" and name == g.logits_layer and self.head_up is not None:
+                self._fused_head_backward(l, dy, grads)
+            elif cls == "Conv2D":
                 if l.config.get("activation") == "relu":
                     # Conv2D(activation="relu"): the gradient of the pre-activation
                     y = self.acts[name]
@@ -992,6 +1033,36 @@ class Trainer:
         self._join_side()
         if self.buckets is not None:
             self.buckets.flush()
+
+    def _fused_head_backward(self, l, dz, grads):
+        """Backward of final_upsampling + head_conv in their half-resolution form (see _fused_head_source)."""
+        lib, st, n = self.lib, self.stream(), self.n
+        name, co = l.name, l.out.c
+        xin, _ = self.saved[name]
+        if l.config["use_bias"]:
+            sums = torch.empty(8, dtype=torch.float64, device=self.dev)
+            L.check(lib.miseg_channel_sums(dz.ptr, dz.pixels, 8, dz.pix, sums.data_ptr(), st))
+            self.gview(name, "bias").copy_(sums[:co])
+        dyt = torch.empty((n, xin.h, xin.w, 32), dtype=torch.bfloat16, device=self.dev)
+        lib.note("head_gather_bwd_kernel", 0, dz.t.numel() * 2 + dyt.numel() * 2)
+        L.check(lib.miseg_head_gather_bwd(dz.ptr, dz.pix, dyt.data_ptr(), n, xin.h, xin.w, co, 32, st))
+        dy = Act(dyt, 32)
+        # the weight gradient's 32 rows are rows c * 9 + tap of the [class][3][3][cin] segment
+        seg = self.segs[(name, "kernel")]
+        cin = _c32(xin.c)
+        self.wgrad(xin, dy.ptr, (32, 32 * xin.w, 32 * xin.w * xin.h), self.G.data_ptr() + 4 * seg.off, cin, 32,
+                   1, 1, 1, 1, 0, 0, xin.h, xin.w, dy_t=dyt)
+        wt = self._dgrad_cache.get(name)
+        if wt is None:
+            rows = self.view(name, "kernel").reshape(-1, cin)[:32]                  # [c * 9 + tap][cin]
+            wt = self._dgrad_cache[name] = rows.t().to(torch.bfloat16).contiguous()  # [cin][32]
+        src_name = self.g.layers[self.head_up].inbound[0]
+
+        def run(res):
+            out = self.new(xin.h, xin.w, xin.c)
+            self.conv(dy, wt.data_ptr(), xin.c, 1, 1, 1, 1, 0, 0, out, xin.h, xin.w, residual=res)
+            return out
+        self._fused_dgrad(grads, src_name, name, dz, run)
 
     def _conv_backward(self, l, dy, grads):
         lib, st, n = self.lib, self.stream(), self.n

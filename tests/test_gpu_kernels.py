@@ -533,7 +533,7 @@ def test_head_gather(env, classes, act, hw):
     out = torch.zeros((n, 2 * h, 2 * w, classes), dtype=torch.float32, device=dev)
     mask = torch.zeros((n, 2 * h, 2 * w, classes), dtype=torch.uint8, device=dev)
     L.check(lib.miseg_head_gather_fwd(yd.data_ptr(), bd.data_ptr(), out.data_ptr(), mask.data_ptr(),
-                                             n, h, w, classes, ypix, act, temp, 127, None))
+                                             n, h, w, classes, ypix, act, temp, 127, 0, None))
     torch.cuda.synchronize()
     got = out.cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
@@ -542,11 +542,55 @@ def test_head_gather(env, classes, act, hw):
     # no mask asked for: the probabilities alone
     out2 = torch.zeros_like(out)
     L.check(lib.miseg_head_gather_fwd(yd.data_ptr(), bd.data_ptr(), out2.data_ptr(), None,
-                                             n, h, w, classes, ypix, act, temp, 127, None))
+                                             n, h, w, classes, ypix, act, temp, 127, 0, None))
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
     assert lib.miseg_head_gather_fwd(yd.data_ptr(), bd.data_ptr(), out2.data_ptr(), None,
-                                            n, h, w, 5, ypix, act, temp, 127, None) != 0
+                                            n, h, w, 5, ypix, act, temp, 127, 0, None) != 0
+
+
+@pytest.mark.parametrize("classes,hw", [(3, (10, 12)), (3, (9, 35)), (1, (8, 32)), (2, (3, 7)), (4, (5, 6))])
+def test_head_gather_backward_is_the_adjoint(env, classes, hw):
+    """miseg_head_gather_bwd against torch autograd through UpSampling2D(bilinear) + the tap sum, in the
+    class-major channel order the training path uses; and the forward in that order."""
+    import torch.nn.functional as F
+    L, lib, dev = env
+    if STORAGE["suffix"]:
+        pytest.skip("training tensors are bf16")
+    rng = np.random.default_rng(23)
+    n, (h, w) = 2, hw
+    ypix = 32 if classes < 4 else 64
+    y = torch.from_numpy(rng.normal(0, 1, (n, h, w, 9 * classes)).astype(np.float32)).requires_grad_(True)
+    # logits[c] = sum_tap shift_tap(upsample(y[c * 9 + tap])), zero outside the image
+    up = F.interpolate(y.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    pad = F.pad(up, (1, 1, 1, 1))
+    H, W = 2 * h, 2 * w
+    logits = torch.stack([sum(pad[:, c * 9 + ky * 3 + kx, ky:ky + H, kx:kx + W] for ky in range(3) for kx in range(3))
+                          for c in range(classes)], dim=-1)
+    dz = bf16_round(rng.normal(0, 1, (n, H, W, classes)))
+    logits.backward(torch.from_numpy(dz))
+    want = y.grad.numpy()
+    dz8 = np.full((n, H, W, 8), 3.0, np.float32)             # channels past `classes` are never read
+    dz8[..., :classes] = dz
+    dzd = dev_bf16(dz8, dev)
+    dy = torch.full((n, h, w, ypix), 9.0, dtype=torch.bfloat16, device=dev)
+    L.check(lib.miseg_head_gather_bwd(dzd.data_ptr(), 8, dy.data_ptr(), n, h, w, classes, ypix, None))
+    torch.cuda.synchronize()
+    got = dy.float().cpu().numpy()
+    assert np.abs(got[..., 9 * classes:]).max() == 0
+    np.testing.assert_allclose(got[..., :9 * classes], want, rtol=2 ** -7, atol=2e-2)
+    assert np.linalg.norm(got[..., :9 * classes] - want) <= 3e-3 * np.linalg.norm(want)
+    # forward, class-major: the same logits
+    yp = np.zeros((n, h, w, ypix), np.float32)
+    yp[..., :9 * classes] = y.detach().numpy()
+    out = torch.zeros((n, H, W, classes), dtype=torch.float32, device=dev)
+    act = 2 if classes > 1 else 3
+    L.check(lib.miseg_head_gather_fwd(dev_f32(yp, dev).data_ptr(), None, out.data_ptr(), None, n, h, w, classes,
+                                      ypix, act, 1.0, 0, 1, None))
+    torch.cuda.synchronize()
+    lg = logits.detach()
+    ref = torch.softmax(lg, dim=-1) if classes > 1 else torch.sigmoid(lg)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
 
 
 def test_prep_input_and_stem(env):

@@ -41,6 +41,17 @@ def forward_errors(tr, weights):
     for name, l in g.layers.items():
         if l.cls == "Conv2D" and name in tr.acts and l.config["kernel_size"] != 7:
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(conv_ref(name)))))
+        elif l.cls == "Conv2D" and name == g.logits_layer and g.activation == "softmax":
+            # the head's probabilities; when the trainer runs final_upsampling + head_conv in their
+            # half-resolution form, the reference is still the plain order of operations
+            xin, pad = tr.saved[name]
+            xf = xin.float().cpu().permute(0, 3, 1, 2)
+            if getattr(tr, "head_up", None):
+                xf = F.interpolate(xf, scale_factor=2, mode="bilinear", align_corners=False)   # never stored
+            wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1)
+            logits = F.conv2d(xf, wt, torch.from_numpy(weights[name]["bias"]), padding=pad).permute(0, 2, 3, 1)
+            ref = torch.softmax(logits / (g.temperature or 1.0), dim=-1)
+            out.append((name, "fwd", _rel(tr.probs.float().cpu(), ref)))
         elif l.cls == "Conv2DTranspose":
             xin, _ = tr.saved[name]
             wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1)
@@ -102,7 +113,19 @@ def backward_errors(tr, weights, x_input):
             continue
         dy, dx = tr.grad_log[name]
         dyf = dy.float().cpu()
-        if l.cls == "Conv2D" and l.config["kernel_size"] != 7:
+        if l.cls == "Conv2D" and name == g.logits_layer and getattr(tr, "head_up", None):
+            # final_upsampling + head_conv run in their half-resolution form: dx is the gradient at the
+            # up-sampling's input
+            xin, pad = tr.saved[name]
+            xf = nchw(xin.float().cpu()).clone().requires_grad_(True)
+            wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1).clone().requires_grad_(True)
+            b = torch.from_numpy(weights[name]["bias"]).clone().requires_grad_(True)
+            up = F.interpolate(xf, scale_factor=2, mode="bilinear", align_corners=False)
+            F.conv2d(up, wt, b, padding=pad).backward(nchw(dyf))
+            out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xf.grad))))
+            out.append((name, "dw", _rel(torch.from_numpy(gw[name]["kernel"]), wt.grad.permute(2, 3, 1, 0))))
+            out.append((name, "dbias", _rel(torch.from_numpy(gw[name]["bias"]), b.grad)))
+        elif l.cls == "Conv2D" and l.config["kernel_size"] != 7:
             xin, pad = tr.saved[name]
             xf = nchw(xin.float().cpu()).clone().requires_grad_(True)
             wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1).clone().requires_grad_(True)
