@@ -143,6 +143,12 @@ class Trainer:
                     self.place[i] = (l.name, c0)
                 c0 += c
         self.head_up = self._fused_head_source()
+        self.fs = self._fused_final_stage()
+        if self.fs is not None:
+            # the aggregated buffer does not exist: its first input gets a tensor of its own
+            for i in list(self.place):
+                if self.place[i][0] == self.fs["cat"]:
+                    del self.place[i]
 
     def _fused_head_source(self):
         """Name of the UpSampling2D(2, 'bilinear') whose only consumer is the 3x3 head convolution (the FPN
@@ -163,6 +169,133 @@ class Trainer:
                 self.consumers[up.name] != [head.name]:
             return None
         return up.name if g.layers[up.inbound[0]].out.c % 32 == 0 else None
+
+    def _fused_final_stage(self):
+        """The FPN decoder's final_stage, a 3x3 convolution of Concatenate([s2, up2(s3), up4(s4), up8(s5)])
+        (nearest up-sampling), in the form that needs none of the up-sampled tensors.  A 3x3 convolution of a
+        nearest-x2 up-sampled tensor is, per output phase, a 2x2 convolution of the tensor itself whose taps
+        are sums of the 3x3 taps that fall on the same source pixel: the four phase convolutions of the
+        transpose-convolution kernels.  So the layer is conv3x3(s2; W[..., :c0]) + T2([s3, up2(s4), up4(s5)]
+        at half resolution; phase weights A W[..., c0:]) in the forward pass, and in the backward pass the
+        gradient of the phase weights goes back through A^T: 58 % of the multiply-adds in all three
+        convolutions of the step.  Returns the layer names involved, or None."""
+        g = self.g
+        if os.environ.get("MISEG_NO_FUSED_FINAL_STAGE"):
+            return None
+        for l in g.layers.values():
+            if l.cls != "Concatenate" or len(l.inbound) != 4 or len(self.consumers[l.name]) != 1:
+                continue
+            conv = g.layers[self.consumers[l.name][0]]
+            ups = [g.layers[i] for i in l.inbound[1:]]
+            fine = g.layers[l.inbound[0]]
+            if conv.cls != "Conv2D" or conv.config["kernel_size"] != 3 or conv.config["strides"] != 1 or \
+                    conv.config["padding"] != "same" or conv.config["use_bias"] or \
+                    conv.config.get("activation") == "relu" or conv.name == g.logits_layer:
+                continue
+            if any(u.cls != "UpSampling2D" or u.config["interpolation"] != "nearest" or
+                   self.consumers[u.name] != [l.name] for u in ups):
+                continue
+            if [u.config["size"] for u in ups] != [2, 4, 8] or fine.out.c % 64 or \
+                    any(u.out.c != fine.out.c for u in ups) or fine.out.h % 2 or fine.out.w % 2 or conv.out.c % 64:
+                continue
+            return {"cat": l.name, "conv": conv.name, "fine": fine.name, "ups": [u.name for u in ups],
+                    "srcs": [u.inbound[0] for u in ups]}
+        return None
+
+    # phase (a, b), tap (dy, dx) of the 2x2 form <- the 3x3 taps (ky, kx) it sums
+    _T2_ROWS = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+
+    def _t2_matrix(self):
+        """A[p][t]: 1 where 3x3 tap t = ky * 3 + kx falls on source tap p = ((a * 2 + b) * 2 + dy) * 2 + dx."""
+        if getattr(self, "_t2_a", None) is None:
+            a_ = torch.zeros((16, 9))
+            for a in range(2):
+                for b in range(2):
+                    for dy in range(2):
+                        for dx in range(2):
+                            for ky in self._T2_ROWS[a][dy]:
+                                for kx in self._T2_ROWS[b][dx]:
+                                    a_[((a * 2 + b) * 2 + dy) * 2 + dx, ky * 3 + kx] = 1.0
+            self._t2_a = a_.to(self.dev)
+        return self._t2_a
+
+    def _final_stage_weights(self):
+        """bf16 operands of the split final_stage from the master copy, once per step: the fine part
+        [co][3][3][c0], the phase weights [4][co][2][2][cc] and the two data-gradient packs."""
+        fs = self.fs
+        cached = self._dgrad_cache.get(fs["conv"])
+        if cached is not None:
+            return cached
+        c0 = self.g.layers[fs["fine"]].out.c
+        k = self.view(fs["conv"], "kernel")                               # [co][3][3][c0 + cc] fp32
+        co, cc = k.shape[0], k.shape[3] - c0
+        fine = k[..., :c0].to(torch.bfloat16).contiguous()
+        wp = torch.einsum("pt,otc->poc", self._t2_matrix(), k[..., c0:].reshape(co, 9, cc))   # [16][co][cc]
+        wp = wp.view(4, 4, co, cc).permute(0, 2, 1, 3).to(torch.bfloat16).contiguous()        # [4][co][2*2][cc]
+        fine_d = fine.float().flip(1, 2).permute(3, 1, 2, 0).to(torch.bfloat16).contiguous()  # [c0][3][3][co]
+        wp_d = wp.view(4, co, 2, 2, cc).permute(0, 4, 2, 3, 1).contiguous()                   # [4][cc][2][2][co]
+        self._dgrad_cache[fs["conv"]] = (fine, wp, fine_d, wp_d)
+        return self._dgrad_cache[fs["conv"]]
+
+    def _final_stage_forward(self, l):
+        fs, lib, st, n = self.fs, self.lib, self.stream(), self.n
+        s2 = self.acts[fs["fine"]]
+        c0, co = s2.c, l.out.c
+        half = self.new(s2.h // 2, s2.w // 2, 3 * c0)
+        for i, src in enumerate(fs["srcs"]):
+            x = self.acts[src]
+            dst = half.slice(i * c0, c0)
+            L.check(lib.miseg_upsample_nearest_fwd(x.ptr, None, dst.ptr, n, x.h, x.w, c0, i, x.pix, 0, dst.pix, st))
+        fine, wp, _, _ = self._final_stage_weights()
+        part = self.new(s2.h, s2.w, co)
+        self.conv(half, wp.data_ptr(), co, 2, 2, 1, 1, 0, 0, part, half.h, half.w, transposed=True)
+        out = self.new_out(l.name, s2.h, s2.w, co)
+        self.conv(s2, fine.data_ptr(), co, 3, 3, 1, 1, 1, 1, out, s2.h, s2.w, residual=part,
+                  stats=self._stats_for(l.name, co))
+        self.acts[l.name] = out
+        self.saved[l.name] = (s2, half)
+
+    def _final_stage_backward(self, l, dy, grads):
+        fs, lib, st, n = self.fs, self.lib, self.stream(), self.n
+        s2, half = self.saved[l.name]
+        c0, co, cc = s2.c, l.out.c, half.c
+        fine, wp, fine_d, wp_d = self._final_stage_weights()
+        dy_str = (dy.pix, dy.pix * dy.w, dy.pix * dy.w * dy.h)
+        # weight gradients of the two parts in their own layouts (main stream: they are folded into the
+        # layer's gradient segment right below)
+        gf = torch.zeros((co, 3, 3, c0), dtype=torch.float32, device=self.dev)    # the kernels accumulate
+        gp = torch.zeros((4, co, 4, cc), dtype=torch.float32, device=self.dev)
+        self.wgrad(s2, dy.ptr, dy_str, gf.data_ptr(), c0, co, 3, 3, 1, 1, 1, 1, s2.h, s2.w, dy_t=dy.t, side=False)
+        for a in range(2):
+            for b in range(2):
+                dyp = dy.ptr + 2 * (a * dy.pix * dy.w + b * dy.pix)
+                self.wgrad(half, dyp, (2 * dy.pix, 2 * dy.pix * dy.w, dy.pix * dy.w * dy.h),
+                           gp.data_ptr() + 4 * (a * 2 + b) * co * 4 * cc, cc, co, 2, 2, 1, 1, 1 - a, 1 - b,
+                           half.h, half.w, dy_t=dy.t, side=False)
+        gk = self.gview(l.name, "kernel")                                 # [co][3][3][c0 + cc]
+        gk[..., :c0] = gf
+        gk[..., c0:] = torch.einsum("pt,poc->otc", self._t2_matrix(),
+                                    gp.permute(0, 2, 1, 3).reshape(16, co, cc)).view(co, 3, 3, cc)
+        # data gradients: the fine part as any 3x3 convolution, the coarse part in one launch of the
+        # transpose-convolution data-gradient mode
+        dyv = Act(dy.t, co, dy.c0)
+
+        def run(res):
+            out = self.new(s2.h, s2.w, c0)
+            self.conv(dyv, fine_d.data_ptr(), c0, 3, 3, 1, 1, 1, 1, out, s2.h, s2.w, residual=res)
+            return out
+        self._fused_dgrad(grads, fs["fine"], l.name, dy, run)
+        dhalf = self.new(half.h, half.w, cc)
+        self.conv(dyv, wp_d.data_ptr(), cc, 2, 2, 1, 1, 0, 0, dhalf, half.h, half.w, transposed=2)
+        for i, src in enumerate(fs["srcs"]):
+            x = self.acts[src]
+            part = dhalf.slice(i * c0, c0)
+            if i == 0:
+                self._accum(grads, src, part)
+                continue
+            dx = self.new(x.h, x.w, c0)
+            L.check(lib.miseg_upsample_nearest_bwd(part.ptr, dx.ptr, n, x.h, x.w, c0, i, part.pix, dx.pix, st))
+            self._accum(grads, src, dx)
 
     def _src(self, name):
         """Skip ZeroPadding2D: returns (producer layer name, accumulated padding)."""
@@ -488,7 +621,7 @@ class Trainer:
         return add.name
 
     def wgrad(self, x, dy_ptr, dy_strides, dw_ptr, cin, cout, kh, kw, sy, sx, py, px, ho, wo,
-              x_geom=None, dy_t=None):
+              x_geom=None, dy_t=None, side=True):
         """dy_t: the tensor behind dy_ptr; it is kept from being recycled until the side stream has
         read it."""
         d = L.WgradDesc()
@@ -504,7 +637,7 @@ class Trainer:
         halo = sx == 1 and sy == 1 and kh == kw and kh <= 3 and cin % 32 == 0 and 0 <= py < kh and 0 <= px < kw
         self.lib.note("wgrad_halo_kernel" if halo else "conv_wgrad_kernel", d.N * ho * wo * cout * kh * kw * cin,
                       d.N * d.H * d.W * cin * 2 + d.N * ho * wo * cout * 2 + cout * kh * kw * cin * 4)
-        if self.side is None:
+        if self.side is None or not side:
             L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.stream()))
             return
         main = torch.cuda.current_stream(self.dev)
@@ -620,6 +753,11 @@ class Trainer:
                     mm.data_ptr() if mm is not None else None, mv.data_ptr() if mv is not None else None,
                     l.config["momentum"], l.config["epsilon"], s["mean"].data_ptr(), s["var"].data_ptr(),
                     s["scale"].data_ptr(), s["shift"].data_ptr(), s["ws"].data_ptr(), st))
+                continue
+            if self.fs is not None and (name == self.fs["cat"] or name in self.fs["ups"]):
+                continue                           # neither the up-sampled tensors nor their concatenation exist
+            if self.fs is not None and name == self.fs["conv"]:
+                self._final_stage_forward(l)
                 continue
             if cls == "Conv2D":
                 src, pad = self._src(l.inbound[0])
@@ -949,6 +1087,8 @@ class Trainer:
                 self.accum_final[name] = dy
             if cls == "Conv2D" and name == g.logits_layer and self.head_up is not None:
                 self._fused_head_backward(l, dy, grads)
+            elif self.fs is not None and name == self.fs["conv"]:
+                self._final_stage_backward(l, dy, grads)
             elif cls == "Conv2D":
                 if l.config.get("activation") == "relu":
                     # Conv2D(activation="relu"): the gradient of the pre-activation

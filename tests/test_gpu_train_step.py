@@ -47,7 +47,9 @@ def test_layerwise_forward_backward(pkg, encoder, decoder, h, w, n):
     tr, weights, x, gt = sc.run(encoder, decoder, h, w, n)
     bad = []
     for name, kind, err in sc.forward_errors(tr, weights):
-        if not err <= 2e-3:                      # only rounding flips may differ
+        # only rounding flips may differ; "fwd-plain": a layer the trainer runs in a split form whose bf16
+        # weights are rounded after a sum of taps, compared with the layer as the graph states it
+        if not err <= (5e-3 if kind == "fwd-plain" else 2e-3):
             bad.append((name, kind, err))
     for name, kind, err in sc.backward_errors(tr, weights, x):
         tol = 6e-3 if kind == "dx" else 2e-3

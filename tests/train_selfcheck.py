@@ -30,8 +30,35 @@ def forward_errors(tr, weights):
     g = tr.g
     out = []
 
-    def conv_ref(name):
+    def conv_ref(name, plain=False):
         l = g.layers[name]
+        fs = getattr(tr, "fs", None)
+        if fs is not None and name == fs["conv"]:
+            # the split final_stage.  Its operands are rounded where the split puts them: the coarse part's
+            # phase weights are sums of 3x3 taps rounded to bf16 AFTER the sum, and the coarse part is stored
+            # (bf16) before it is added.  `plain` = the layer as the graph states it.
+            k = torch.from_numpy(weights[name]["kernel"])                       # (3, 3, cin, co) fp32
+            xs = [tr.acts[n_].float().cpu().permute(0, 3, 1, 2) for n_ in [fs["fine"]] + fs["srcs"]]
+            c0 = xs[0].shape[1]
+            if plain:
+                ups = [xs[0]] + [F.interpolate(x, scale_factor=2 << i, mode="nearest") for i, x in enumerate(xs[1:])]
+                return F.conv2d(torch.cat(ups, dim=1), _bf(k).permute(3, 2, 0, 1), None, padding=1).permute(0, 2, 3, 1)
+            half = torch.cat([xs[1]] + [F.interpolate(x, scale_factor=2 << i, mode="nearest")
+                                        for i, x in enumerate(xs[2:])], dim=1)
+            hp = F.pad(half, (1, 1, 1, 1))
+            h, w = half.shape[2:]
+            coarse = torch.zeros((half.shape[0], k.shape[3], 2 * h, 2 * w))
+            rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+            for a in range(2):
+                for b in range(2):
+                    w2 = torch.zeros((k.shape[3], k.shape[2] - c0, 2, 2))
+                    for dy in range(2):
+                        for dx in range(2):
+                            w2[:, :, dy, dx] = _bf(sum(k[ky, kx, c0:, :] for ky in rows[a][dy]
+                                                       for kx in rows[b][dx])).t()
+                    coarse[:, :, a::2, b::2] = F.conv2d(hp, w2)[:, :, a:a + h, b:b + w]
+            fine = F.conv2d(xs[0], _bf(k[:, :, :c0, :]).permute(3, 2, 0, 1), None, padding=1)
+            return (fine + _bf(coarse)).permute(0, 2, 3, 1)
         xin, pad = tr.saved[name]
         wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1)
         b = torch.from_numpy(weights[name]["bias"]) if "bias" in weights[name] else None
@@ -41,6 +68,10 @@ def forward_errors(tr, weights):
     for name, l in g.layers.items():
         if l.cls == "Conv2D" and name in tr.acts and l.config["kernel_size"] != 7:
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(conv_ref(name)))))
+            if getattr(tr, "fs", None) and name == tr.fs["conv"]:
+                # against the layer as stated the split differs by the rounding of its weights (2^-9 per
+                # phase weight, as for any bf16 weight): a wider bar applies to this entry
+                out.append((name, "fwd-plain", _rel(tr.acts[name].float().cpu(), _bf(conv_ref(name, True)))))
         elif l.cls == "Conv2D" and name == g.logits_layer and g.activation == "softmax":
             # the head's probabilities; when the trainer runs final_upsampling + head_conv in their
             # half-resolution form, the reference is still the plain order of operations
@@ -78,7 +109,7 @@ def forward_errors(tr, weights):
                 return conv_ref(i)
             parts = [part(i) for i in l.inbound]
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(parts[0] + parts[1]))))
-        elif l.cls == "Concatenate":
+        elif l.cls == "Concatenate" and name in tr.acts:
             ref = torch.cat([tr.acts[i].float().cpu() for i in l.inbound], dim=-1)
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), ref)))
         elif l.cls == "MaxPooling2D":
@@ -113,7 +144,21 @@ def backward_errors(tr, weights, x_input):
             continue
         dy, dx = tr.grad_log[name]
         dyf = dy.float().cpu()
-        if l.cls == "Conv2D" and name == g.logits_layer and getattr(tr, "head_up", None):
+        fs = getattr(tr, "fs", None)
+        if fs is not None and name == fs["conv"]:
+            # the split final_stage against the plain layer: gradients at s2 (dx), at the three coarser
+            # tensors (through their nearest up-sampling) and of the whole kernel
+            xs = [nchw(tr.acts[n_].float().cpu()).clone().requires_grad_(True) for n_ in [fs["fine"]] + fs["srcs"]]
+            ups = [xs[0]] + [F.interpolate(x, scale_factor=2 << i, mode="nearest") for i, x in enumerate(xs[1:])]
+            wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1).clone().requires_grad_(True)
+            F.conv2d(torch.cat(ups, dim=1), wt, None, padding=1).backward(nchw(dyf))
+            out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xs[0].grad))))
+            out.append((name, "dw", _rel(torch.from_numpy(gw[name]["kernel"]), wt.grad.permute(2, 3, 1, 0))))
+            for n_, x in zip(fs["srcs"], xs[1:]):
+                parts = tr.accum_log[n_]
+                assert len(parts) == 1
+                out.append((name + "->" + n_, "dx", _rel(parts[0].float().cpu(), nhwc(x.grad))))
+        elif l.cls == "Conv2D" and name == g.logits_layer and getattr(tr, "head_up", None):
             # final_upsampling + head_conv run in their half-resolution form: dx is the gradient at the
             # up-sampling's input
             xin, pad = tr.saved[name]
