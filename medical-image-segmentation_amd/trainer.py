@@ -144,6 +144,8 @@ class Trainer:
                 c0 += c
         self.head_up = self._fused_head_source()
         self.fs = self._fused_final_stage()
+        self.p2 = self._folded_finest_level()
+        self._ones = {}
         if self.fs is not None:
             # the aggregated buffer does not exist: its first input gets a tensor of its own
             for i in list(self.place):
@@ -201,6 +203,134 @@ class Trainer:
             return {"cat": l.name, "conv": conv.name, "fine": fine.name, "ups": [u.name for u in ups],
                     "srcs": [u.inbound[0] for u in ups]}
         return None
+
+    def _folded_finest_level(self):
+        """The FPN decoder's finest pyramid level, p2 = Add(up2(p3), lateral(skip) + bias), whose only consumer
+        is a 3x3 convolution (segm_stage2a): by linearity, zero padding included,
+            conv3x3(W3; p2) = T2(q3; A W3) + conv3x3(Wc; skip),  q3 = p3 + bias,  Wc[t] = W_l W3[t],
+        the phase convolution of _fused_final_stage on the level above plus a 3x3 convolution of the skip tensor
+        with the composed kernel.  p2 (256 channels at half resolution), its 1x1 convolution, the up-sampling
+        and the Add never run; the backward applies the product rule to Wc and A^T to the phase weights.
+        Returns the layer names involved, or None."""
+        g = self.g
+        if os.environ.get("MISEG_NO_FOLDED_P2"):
+            return None
+        for add in g.layers.values():
+            if add.cls != "Add" or len(add.inbound) != 2 or len(self.consumers[add.name]) != 1:
+                continue
+            conv = g.layers[self.consumers[add.name][0]]
+            a, b = (g.layers[i] for i in add.inbound)
+            up, lat = (a, b) if a.cls == "UpSampling2D" else (b, a)
+            if conv.cls != "Conv2D" or conv.config["kernel_size"] != 3 or conv.config["strides"] != 1 or \
+                    conv.config["padding"] != "same" or conv.config["use_bias"] or conv.name in self.frozen or \
+                    conv.config.get("activation") == "relu" or conv.name == g.logits_layer or conv.out.c % 64:
+                continue
+            if up.cls != "UpSampling2D" or up.config["interpolation"] != "nearest" or up.config["size"] != 2 or \
+                    self.consumers[up.name] != [add.name] or up.out.c % 64:
+                continue
+            if lat.cls != "Conv2D" or lat.config["kernel_size"] != 1 or lat.config["strides"] != 1 or \
+                    not lat.config["use_bias"] or lat.config.get("activation") == "relu" or \
+                    self.consumers[lat.name] != [add.name] or lat.name in self.frozen:
+                continue
+            skip = self._src(lat.inbound[0])[0]
+            if g.layers[skip].out.c % 32 or g.layers[skip].cls == "InputLayer":
+                continue
+            return {"add": add.name, "conv": conv.name, "up": up.name, "lat": lat.name, "skip": skip,
+                    "coarse": up.inbound[0]}
+        return None
+
+    def _p2_weights(self):
+        """Operands of the folded level from the bf16 working copies, once per step: the composed kernel
+        [co][3][3][cs], the phase weights [4][co][2][2][cp], their data-gradient packs, and the two factors
+        (fp32 values of the bf16 copies) the product rule needs."""
+        p2 = self.p2
+        cached = self._dgrad_cache.get(p2["conv"])
+        if cached is not None:
+            return cached
+        sg3, sgl = self.segs[(p2["conv"], "kernel")], self.segs[(p2["lat"], "kernel")]
+        w3 = self.PB[sg3.off:sg3.off + sg3.count].view(sg3.shape).float()          # [co][3][3][cp]
+        cp = self.g.layers[p2["coarse"]].out.c
+        cs = self.g.layers[p2["skip"]].out.c
+        wl = self.PB[sgl.off:sgl.off + sgl.count].view(sgl.shape).float()[:cp, 0, 0, :cs]   # [cp][cs]
+        w3 = w3[..., :cp]
+        co = w3.shape[0]
+        wc = torch.einsum("otc,cs->ots", w3.reshape(co, 9, cp), wl).to(torch.bfloat16).contiguous()   # [co][9][cs]
+        wp32 = torch.einsum("pt,otc->poc", self._t2_matrix(), w3.reshape(co, 9, cp))
+        wp32 = wp32.view(4, 4, co, cp).permute(0, 2, 1, 3).contiguous()                      # [4][co][2*2][cp]
+        wp = wp32.to(torch.bfloat16)
+        wc_d = wc.view(co, 3, 3, cs).float().flip(1, 2).permute(3, 1, 2, 0).to(torch.bfloat16).contiguous()
+        wp_d = wp.view(4, co, 2, 2, cp).permute(0, 4, 2, 3, 1).contiguous()
+        self._dgrad_cache[p2["conv"]] = (wc, wp, wc_d, wp_d, w3.reshape(co, 9, cp), wl, wp32)
+        return self._dgrad_cache[p2["conv"]]
+
+    def _p2_forward(self, l):
+        p2, st, n = self.p2, self.stream(), self.n
+        p3, skip = self.acts[p2["coarse"]], self.acts[p2["skip"]]
+        co, cp = l.out.c, p3.c
+        wc, wp = self._p2_weights()[:2]
+        # q3 = p3 + the lateral convolution's bias (constant under nearest up-sampling, and inside the zero
+        # padding's border like the tensor it is added to)
+        q3 = self.new(p3.h, p3.w, cp)
+        torch.add(p3.t[..., p3.c0:p3.c0 + cp], self.view(p2["lat"], "bias"), out=q3.t)   # fp32 sum, stored bf16
+        part = self.new(skip.h, skip.w, co)
+        self.conv(q3, wp.data_ptr(), co, 2, 2, 1, 1, 0, 0, part, q3.h, q3.w, transposed=True)
+        out = self.new_out(l.name, skip.h, skip.w, co)
+        self.conv(skip, wc.data_ptr(), co, 3, 3, 1, 1, 1, 1, out, skip.h, skip.w, residual=part,
+                  stats=self._stats_for(l.name, co))
+        self.acts[l.name] = out
+        self.saved[l.name] = (skip, q3)
+
+    def _p2_backward(self, l, dy, grads):
+        p2, lib, st, n = self.p2, self.lib, self.stream(), self.n
+        skip, q3 = self.saved[l.name]
+        co, cp, cs = l.out.c, q3.c, skip.c
+        wc, wp, wc_d, wp_d, w3, wl, wp32 = self._p2_weights()
+        dy_str = (dy.pix, dy.pix * dy.w, dy.pix * dy.w * dy.h)
+        csp = _c32(cs)
+        gc = torch.zeros((co, 9, csp), dtype=torch.float32, device=self.dev)      # the kernels accumulate
+        gp = torch.zeros((4, co, 4, cp), dtype=torch.float32, device=self.dev)
+        self.wgrad(skip, dy.ptr, dy_str, gc.data_ptr(), csp, co, 3, 3, 1, 1, 1, 1, skip.h, skip.w, dy_t=dy.t,
+                   side=False)
+        for a in range(2):
+            for b in range(2):
+                dyp = dy.ptr + 2 * (a * dy.pix * dy.w + b * dy.pix)
+                self.wgrad(q3, dyp, (2 * dy.pix, 2 * dy.pix * dy.w, dy.pix * dy.w * dy.h),
+                           gp.data_ptr() + 4 * (a * 2 + b) * co * 4 * cp, cp, co, 2, 2, 1, 1, 1 - a, 1 - b,
+                           q3.h, q3.w, dy_t=dy.t, side=False)
+        gc = gc[..., :cs]
+        # product rule on Wc[o][t][s] = sum_c W3[o][t][c] Wl[c][s]; A^T on the phase weights
+        g3 = torch.einsum("ots,cs->otc", gc, wl) + \
+            torch.einsum("pt,poc->otc", self._t2_matrix(), gp.permute(0, 2, 1, 3).reshape(16, co, cp))
+        self.gview(l.name, "kernel")[..., :cp] = g3.view(co, 3, 3, cp)
+        self.gview(p2["lat"], "kernel")[:cp, 0, 0, :cs] = torch.einsum("otc,ots->cs", w3, gc)
+        dyv = Act(dy.t, co, dy.c0)
+        dq3 = self.new(q3.h, q3.w, cp)
+        self.conv(dyv, wp_d.data_ptr(), cp, 2, 2, 1, 1, 0, 0, dq3, q3.h, q3.w, transposed=2)
+        # bias gradient = the sum of dq3 over all pixels, taken before dq3 is rounded to bf16 (its entries cancel):
+        # sum_pix dq3[c] = sum_{phase, tap, o} Wp[phase][o][tap][c] S[phase][o][tap], S = the sums of dY over the
+        # output pixels whose source pixel for that tap lies inside the image -- which is what the phase weight
+        # gradient of an all-ones input channel holds (fp32 accumulation, the border handled by its zero padding)
+        key = (q3.h, q3.w)
+        if self._ones.get("key") != key:
+            self._ones = {"key": key, "t": torch.ones((n, q3.h, q3.w, 32), dtype=torch.bfloat16, device=self.dev)}
+        ones = Act(self._ones["t"], 32)
+        gs = torch.zeros((4, co, 4, 32), dtype=torch.float32, device=self.dev)
+        for a in range(2):
+            for b in range(2):
+                dyp = dy.ptr + 2 * (a * dy.pix * dy.w + b * dy.pix)
+                self.wgrad(ones, dyp, (2 * dy.pix, 2 * dy.pix * dy.w, dy.pix * dy.w * dy.h),
+                           gs.data_ptr() + 4 * (a * 2 + b) * co * 4 * 32, 32, co, 2, 2, 1, 1, 1 - a, 1 - b,
+                           q3.h, q3.w, dy_t=dy.t, side=False)
+        self.gview(p2["lat"], "bias").copy_(torch.einsum("pokc,pok->c", wp32, gs[..., 0]))
+        if self.grad_log is not None:
+            self.grad_log[p2["add"]] = (dy, dq3)       # for checks: the gradient at the level above
+        self._accum(grads, p2["coarse"], dq3)
+
+        def run(res):
+            out = self.new(skip.h, skip.w, cs)
+            self.conv(dyv, wc_d.data_ptr(), cs, 3, 3, 1, 1, 1, 1, out, skip.h, skip.w, residual=res)
+            return out
+        self._fused_dgrad(grads, p2["skip"], l.name, dy, run)
 
     # phase (a, b), tap (dy, dx) of the 2x2 form <- the 3x3 taps (ky, kx) it sums
     _T2_ROWS = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
@@ -759,6 +889,11 @@ class Trainer:
             if self.fs is not None and name == self.fs["conv"]:
                 self._final_stage_forward(l)
                 continue
+            if self.p2 is not None and name in (self.p2["lat"], self.p2["up"], self.p2["add"]):
+                continue                           # folded into the 3x3 convolution that consumes the level
+            if self.p2 is not None and name == self.p2["conv"]:
+                self._p2_forward(l)
+                continue
             if cls == "Conv2D":
                 src, pad = self._src(l.inbound[0])
                 k = l.config["kernel_size"]
@@ -1089,6 +1224,8 @@ class Trainer:
                 self._fused_head_backward(l, dy, grads)
             elif self.fs is not None and name == self.fs["conv"]:
                 self._final_stage_backward(l, dy, grads)
+            elif self.p2 is not None and name == self.p2["conv"]:
+                self._p2_backward(l, dy, grads)
             elif cls == "Conv2D":
                 if l.config.get("activation") == "relu":
                     # Conv2D(activation="relu"): the gradient of the pre-activation

@@ -59,6 +59,35 @@ def forward_errors(tr, weights):
                     coarse[:, :, a::2, b::2] = F.conv2d(hp, w2)[:, :, a:a + h, b:b + w]
             fine = F.conv2d(xs[0], _bf(k[:, :, :c0, :]).permute(3, 2, 0, 1), None, padding=1)
             return (fine + _bf(coarse)).permute(0, 2, 3, 1)
+        p2 = getattr(tr, "p2", None)
+        if p2 is not None and name == p2["conv"]:
+            # the folded finest FPN level: 3x3 convolution of the skip tensor with the composed kernel plus the
+            # phase convolution of q3 = p3 + bias; operands rounded where the fold rounds them.  `plain` = the
+            # layers as the graph states them (lateral 1x1 + bias, up-sampling, Add, 3x3), each stored in bf16.
+            k3 = _bf(torch.from_numpy(weights[name]["kernel"]))                   # (3, 3, cp, co)
+            kl = _bf(torch.from_numpy(weights[p2["lat"]]["kernel"]))[0, 0]        # (cs, cp)
+            bl = torch.from_numpy(weights[p2["lat"]]["bias"])
+            p3 = tr.acts[p2["coarse"]].float().cpu().permute(0, 3, 1, 2)
+            sk = tr.acts[p2["skip"]].float().cpu().permute(0, 3, 1, 2)
+            if plain:
+                lat = _bf(F.conv2d(sk, kl.t()[:, :, None, None], bl))
+                x = _bf(F.interpolate(p3, scale_factor=2, mode="nearest") + lat)
+                return F.conv2d(x, k3.permute(3, 2, 0, 1), None, padding=1).permute(0, 2, 3, 1)
+            q3 = _bf(p3 + bl[None, :, None, None])
+            hp = F.pad(q3, (1, 1, 1, 1))
+            h, w = q3.shape[2:]
+            coarse = torch.zeros((q3.shape[0], k3.shape[3], 2 * h, 2 * w))
+            rows = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+            for a in range(2):
+                for b in range(2):
+                    w2 = torch.zeros((k3.shape[3], k3.shape[2], 2, 2))
+                    for dy in range(2):
+                        for dx in range(2):
+                            w2[:, :, dy, dx] = _bf(sum(k3[ky, kx] for ky in rows[a][dy] for kx in rows[b][dx])).t()
+                    coarse[:, :, a::2, b::2] = F.conv2d(hp, w2)[:, :, a:a + h, b:b + w]
+            wc = _bf(torch.einsum("sc,yxco->yxso", kl, k3))                       # (3, 3, cs, co)
+            fine = F.conv2d(sk, wc.permute(3, 2, 0, 1), None, padding=1)
+            return (fine + _bf(coarse)).permute(0, 2, 3, 1)
         xin, pad = tr.saved[name]
         wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1)
         b = torch.from_numpy(weights[name]["bias"]) if "bias" in weights[name] else None
@@ -68,7 +97,7 @@ def forward_errors(tr, weights):
     for name, l in g.layers.items():
         if l.cls == "Conv2D" and name in tr.acts and l.config["kernel_size"] != 7:
             out.append((name, "fwd", _rel(tr.acts[name].float().cpu(), _bf(conv_ref(name)))))
-            if getattr(tr, "fs", None) and name == tr.fs["conv"]:
+            if (getattr(tr, "fs", None) and name == tr.fs["conv"]) or (getattr(tr, "p2", None) and name == tr.p2["conv"]):
                 # against the layer as stated the split differs by the rounding of its weights (2^-9 per
                 # phase weight, as for any bf16 weight): a wider bar applies to this entry
                 out.append((name, "fwd-plain", _rel(tr.acts[name].float().cpu(), _bf(conv_ref(name, True)))))
@@ -96,7 +125,7 @@ def forward_errors(tr, weights):
             ref = torch.relu((xf - mean) * torch.rsqrt(var + l.config["epsilon"]) * gam
                              + torch.from_numpy(weights[name]["beta"]))
             out.append((name, "fwd", _rel(tr.acts[tr.consumers[name][0]].float().cpu(), _bf(ref))))
-        elif l.cls == "Add":
+        elif l.cls == "Add" and name in tr.acts:
             # an input the trainer never stored is a convolution whose epilogue did the addition: its
             # (unrounded) result enters the reference instead
             def part(i):
@@ -158,6 +187,25 @@ def backward_errors(tr, weights, x_input):
                 parts = tr.accum_log[n_]
                 assert len(parts) == 1
                 out.append((name + "->" + n_, "dx", _rel(parts[0].float().cpu(), nhwc(x.grad))))
+        elif getattr(tr, "p2", None) and name == tr.p2["conv"]:
+            # the folded finest FPN level against the layers as the graph states them
+            p2 = tr.p2
+            p3 = nchw(tr.acts[p2["coarse"]].float().cpu()).clone().requires_grad_(True)
+            sk = nchw(tr.acts[p2["skip"]].float().cpu()).clone().requires_grad_(True)
+            w3 = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1).clone().requires_grad_(True)
+            wl = _bf(torch.from_numpy(weights[p2["lat"]]["kernel"])).permute(3, 2, 0, 1).clone().requires_grad_(True)
+            bl = torch.from_numpy(weights[p2["lat"]]["bias"]).clone().requires_grad_(True)
+            # q3 = p3 + bias is stored (bf16) by the fold, as p2 is by the plain layers: the same rounding
+            # here, with a straight-through gradient
+            q3 = p3 + bl[None, :, None, None]
+            q3 = q3 + (_bf(q3) - q3).detach()
+            x = F.interpolate(q3, scale_factor=2, mode="nearest") + F.conv2d(sk, wl, None)
+            F.conv2d(x, w3, None, padding=1).backward(nchw(dyf))
+            out.append((name, "dx", _rel(dx.float().cpu(), nhwc(sk.grad))))
+            out.append((name + "->" + p2["coarse"], "dx", _rel(tr.grad_log[p2["add"]][1].float().cpu(), nhwc(p3.grad))))
+            out.append((name, "dw", _rel(torch.from_numpy(gw[name]["kernel"]), w3.grad.permute(2, 3, 1, 0))))
+            out.append((p2["lat"], "dw", _rel(torch.from_numpy(gw[p2["lat"]]["kernel"]), wl.grad.permute(2, 3, 1, 0))))
+            out.append((p2["lat"], "dbias", _rel(torch.from_numpy(gw[p2["lat"]]["bias"]), bl.grad)))
         elif l.cls == "Conv2D" and name == g.logits_layer and getattr(tr, "head_up", None):
             # final_upsampling + head_conv run in their half-resolution form: dx is the gradient at the
             # up-sampling's input
