@@ -14,6 +14,7 @@
 // the 16-byte chunk index XOR-swizzled on the source side.  Partial tiles are added to the
 // fp32 gradient with float atomics (two 128-byte row segments per wave instruction).
 #include "common.h"
+#include <cmath>
 
 #include <type_traits>
 
@@ -415,6 +416,19 @@ static void launch_halo_wgrad(const WgradParams& p, hipStream_t stream) {
   const int ntiles = p.N * ((p.Ho + 7) / 8) * ((p.Wo + 31) / 32);
   int nb = (1024 + pairs - 1) / pairs;                  // ~4 resident blocks per CU over all pairs
   if (nb > ntiles) nb = ntiles;
+  {
+    // Every block ends by adding its whole weight tile to memory with atomics, whose total count is what a
+    // launch with few pixel tiles per block spends its time on (DenseNet's 128 -> 32 layers at 240x320 x 4:
+    // 1024 blocks x 36 864 atomics for 2.3 tiles of arithmetic each, 0.21 ms; 0.09 ms with a quarter of the
+    // blocks).  Blocks per pair that balance the two: flush ~ nb * pairs * A, arithmetic ~ ntiles * t / nb.
+    const int cot = co64 ? 64 : 32, cit = ci64 ? 64 : 32;
+    const int wk = 4 / ((cot / 32) * (cit / 32));
+    const double A = (double)cot * cit * KH * KW * wk;              // atomics per block
+    const double tt = 0.25 + 0.25 * KH * KW * (wk == 1 ? 2 : 1);    // relative time of one pixel tile
+    int best = (int)(sqrt((double)ntiles * 6.0e5 * tt / (pairs * A)) + 0.5);
+    if (best < 1) best = 1;
+    if (best < nb) nb = best;
+  }
   const dim3 grid((unsigned)nb, (unsigned)pairs);
   if (co64 && ci64)
     hipLaunchKernelGGL((wgrad_halo_kernel<KH, KW, 64, 64>), grid, dim3(256), 0, stream, q);
