@@ -152,6 +152,12 @@ typedef struct miseg_conv_desc {
                                  FPNBlock, reached from utils/model.py:200-211) */
   int32_t out2_linear;        /* non-zero: the second output without its ReLU, out2 = v * scale2 + shift2 (a
                                  biased copy of the result: the engine's split form of FPN's segm_stage2a) */
+  int32_t in_valid_c;         /* 0, or a multiple of 8 below Cin: only the first in_valid_c channels of an input
+                                 pixel exist in memory (in_pix_stride may then be as small as in_valid_c), the rest
+                                 of the Cin channels read as zero.  The training path's gradient at the logits is
+                                 stored 8 channels wide, and the head convolution's data gradient reads it so.
+                                 Taken by 3x3 stride-1 layers with Cin = 32, Cout <= 32 and 16-bit output without
+                                 residual or second output; MISEG_E_UNSUPPORTED_SHAPE otherwise */
 } miseg_conv_desc;
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);

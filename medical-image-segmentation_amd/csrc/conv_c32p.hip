@@ -117,7 +117,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
       int h = hl[j];
       asm volatile("" : "+v"(h));   // keep the unpacking inside the loop
       const int hy = h & 255, hx = (h >> 8) & 255, sl = h >> 16;
-      const bool ok = h >= 0 && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+      // (channels from in_valid_c on do not exist in memory and read as zero)
+      const bool ok = h >= 0 && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W &&
+                      sl * 8 < p.in_valid_c;
       const unsigned char* src = ok ? base + (hy * p.in_row_stride + hx * p.in_pix_stride + sl * 8) * 2 : zero_src;
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,

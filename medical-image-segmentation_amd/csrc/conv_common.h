@@ -60,6 +60,7 @@ struct ConvParams {
   int res_shift;         // the residual is read at (oy >> res_shift, ox >> res_shift): nearest up-sampling
   int res_after;         // the residual is added after the activation (out = act(v) + residual)
   int dgrad_t;           // data gradient of Conv2DTranspose(4, 2): `in` is dY, taps run over its four phase lattices
+  int in_valid_c;        // channels of an input pixel that exist in memory (the rest read as zero); Cin when all do
 };
 
 // 16 zero bytes x 8: the source of LDS-DMA loads for taps that fall outside the image.

@@ -689,6 +689,8 @@ int validate_conv(const miseg_conv_desc* d) {
   }
   MISEG_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->stride_y > 0 && d->stride_x > 0,
                   "conv: bad kernel/stride");
+  MISEG_CHECK_ARG(d->in_valid_c >= 0 && (d->in_valid_c & 7) == 0 && d->in_valid_c < d->Cin,
+                  "conv: in_valid_c must be 0 or a multiple of 8 below Cin");
   MISEG_CHECK_ARG((d->in_pix_stride & 7) == 0 && (d->in_row_stride & 7) == 0 &&
                       (d->in_img_stride & 7) == 0,
                   "conv: input strides must be multiples of 8 elements (16-byte loads)");
@@ -906,6 +908,7 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.res_after = d->res_after_act ? 1 : 0;
   p.res_shift = d->res_upsample_shift;
   p.out2_linear = d->out2_linear ? 1 : 0;
+  p.in_valid_c = d->in_valid_c > 0 ? d->in_valid_c : d->Cin;
   // one million output pixels: from there on the epilogue's HBM traffic, not its latency, is what a generic
   // launch waits for (measured on the full-resolution 1x1 layers of LinkNet and FPN: 1.1-2.2x faster)
   p.direct = (long long)d->N * d->Ho * d->Wo >= (1 << 20);
@@ -930,6 +933,11 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   if (rc != MISEG_OK) return rc;
   ConvParams p;
   fill_params(d, p);
+  if (d->in_valid_c > 0 && (d->transposed || choose_kernel(d).kind != K_C32 || !conv_c32p_ok(p) ||
+                            (d->tile_hint & MISEG_TILE_NO_PERSIST))) {
+    set_error("conv: in_valid_c needs a 3x3 stride-1 layer with Cin = 32, Cout <= 32, 16-bit output, no residual");
+    return MISEG_E_UNSUPPORTED_SHAPE;
+  }
   if (d->transposed == MISEG_CONV_DGRAD_T) {
     // dX = sum over the four phase lattices of dY: one launch of the ring kernel in its data-gradient mode
     p.transposed = 0;

@@ -43,6 +43,7 @@ class ConvDesc(C.Structure):
         ("stats", C.c_void_p), ("stats_replicas", C.c_int32), ("stats_stride", C.c_int32),
         ("fmt", C.c_int32), ("res_after_act", C.c_int32), ("res_upsample_shift", C.c_int32),
         ("out2_linear", C.c_int32),
+        ("in_valid_c", C.c_int32),
     ]
 
 

@@ -616,14 +616,16 @@ class Trainer:
         return buf.slice(c0, c)
 
     def conv(self, x, wptr, cout, kh, kw, sy, sx, py, px, out, ho, wo, bias=None, transposed=False,
-             out_view=None, act=L.ACT_NONE, probs=None, temperature=1.0, residual=None, stats=None):
+             out_view=None, act=L.ACT_NONE, probs=None, temperature=1.0, residual=None, stats=None,
+             in_valid_c=0):
         """out_view: (ptr, pix, row, img) to address a strided lattice; default = dense `out`.
         stats: zeroed fp64 buffer of (STAT_REPLICAS + 1) * 2 * _c32(cout) entries that receives the
         per-channel sum and sum of squares of the stored output (for a following BatchNormalization)."""
         d = L.ConvDesc()
         d.inp, d.weight = x.ptr, wptr
         d.N, d.H, d.W, d.Cin = x.n, x.h, x.w, _c32(x.c)
-        assert x.c0 + d.Cin <= x.pix, "input view lacks channel padding"
+        assert x.c0 + (in_valid_c or d.Cin) <= x.pix, "input view lacks channel padding"
+        d.in_valid_c = in_valid_c
         d.Ho, d.Wo, d.Cout = ho, wo, cout
         d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
         d.in_pix_stride, d.in_row_stride, d.in_img_stride = x.pix, x.pix * x.w, x.pix * x.w * x.h
@@ -666,7 +668,7 @@ class Trainer:
         taps = d.KH * d.KW * (4 if d.transposed else 1)
         opix = d.N * d.Ho * d.Wo * (4 if d.transposed == 1 else 1)
         macs = d.N * d.Ho * d.Wo * d.Cout * taps * d.Cin
-        nbytes = x.n * x.h * x.w * d.Cin * 2 + d.Cout * taps * d.Cin * 2 + \
+        nbytes = x.n * x.h * x.w * (d.in_valid_c or d.Cin) * 2 + d.Cout * taps * d.Cin * 2 + \
             opix * d.Cout * ((4 if f32_out else 2) + (2 if has_res else 0))
         self.lib.note(buf.value.decode(), macs, nbytes)
 
@@ -1188,7 +1190,10 @@ class Trainer:
         self.accum_log, self.accum_final = {}, {}
         c = self.classes
         head = g.layers[g.logits_layer]
-        dzc = 8 if self.head_up is not None else 32          # the fused head reads `classes` channels per pixel
+        # the fused head reads `classes` channels per pixel, and so do a plain 3x3 head's gradient kernels when
+        # its input has at most 32 channels and no other consumer (miseg_conv_desc.in_valid_c); otherwise the
+        # gradient is a 32-channel tensor like any other
+        dzc = 8 if self.head_up is not None or self._narrow_dz(head) else 32
         dz = torch.empty((n, self.H, self.W, dzc), dtype=torch.bfloat16, device=self.dev)   # the kernel zero-pads
         temp = g.temperature if g.temperature else 1.0
         L.check(lib.miseg_loss_grad_ex(self.gt.data_ptr(), self.probs.data_ptr(), self.loss_sums.data_ptr(),
@@ -1311,6 +1316,15 @@ class Trainer:
         if self.buckets is not None:
             self.buckets.flush()
 
+    def _narrow_dz(self, head):
+        if head.cls != "Conv2D" or head.config["kernel_size"] != 3 or head.config["strides"] != 1 or \
+                os.environ.get("MISEG_WIDE_DZ") or self.classes > 8:
+            return False
+        src = self._src(head.inbound[0])[0]
+        sl = self.g.layers[src]
+        return sl.cls != "InputLayer" and _c32(sl.out.c) == 32 and self.consumers[head.inbound[0]] == [head.name] \
+            and len(self.consumers[src]) == 1 and head.name not in self.frozen
+
     def _fused_head_backward(self, l, dz, grads):
         """Backward of final_upsampling + head_conv in their half-resolution form (see _fused_head_source)."""
         lib, st, n = self.lib, self.stream(), self.n
@@ -1349,8 +1363,9 @@ class Trainer:
         co = l.out.c
         cop = _c32(co)
         if l.config["use_bias"]:
-            sums = torch.empty(cop, dtype=torch.float64, device=self.dev)
-            L.check(lib.miseg_channel_sums(dy.ptr, dy.pixels, cop, dy.pix, sums.data_ptr(), st))
+            cs = min(cop, dy.pix)                     # (the gradient at the logits may be 8 channels wide)
+            sums = torch.empty(cs, dtype=torch.float64, device=self.dev)
+            L.check(lib.miseg_channel_sums(dy.ptr, dy.pixels, cs, dy.pix, sums.data_ptr(), st))
             self.gview(name, "bias").copy_(sums[:co])
         seg = self.segs[(name, "kernel")]
         dw_ptr = self.G.data_ptr() + 4 * seg.off
@@ -1386,10 +1401,12 @@ class Trainer:
         packs = self.dgrad_weight(l)
         dyv = Act(dy.t, cop, dy.c0)
         if stride == 1:
+            narrow = dy.pix if dy.pix < cop else 0
+
             def run(res):
                 out = self.new(xin.h, xin.w, ci)
                 self.conv(dyv, packs[0].data_ptr(), ci, k, k, 1, 1, k - 1 - pad, k - 1 - pad, out, xin.h,
-                          xin.w, residual=res)
+                          xin.w, residual=res, in_valid_c=narrow)
                 return out
             self._fused_dgrad(grads, src_name, l.name, dy, run)
             return

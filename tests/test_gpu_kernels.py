@@ -593,6 +593,42 @@ def test_head_gather_backward_is_the_adjoint(env, classes, hw):
     np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", [(2, 17, 40, 8, 32), (1, 8, 32, 8, 16), (1, 9, 33, 16, 32)])
+def test_conv_narrow_input(env, shape):
+    """in_valid_c: a 3x3 layer with Cin = 32 whose input pixels hold only the first 8 (16) channels in memory
+    (pixel stride = that count); the missing channels read as zero, whatever the weights there."""
+    from oracle import ops_np
+    L, lib, dev = env
+    n, h, w, cv, cout = shape
+    rng = np.random.default_rng(31)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cv)))
+    k = bf16_round(rng.normal(0, 0.2, (3, 3, 32, cout)))          # taps for all 32 channels, 24 of them unused
+    want = ops_np.conv2d(x, k[:, :, :cv], pad=1)
+    xin, wt = dev_bf16(x, dev), dev_bf16(k.transpose(3, 0, 1, 2), dev)
+    out = torch.zeros((n, h, w, cout), dtype=h16(), device=dev)
+    d = new_desc(L)
+    d.inp, d.weight, d.out = xin.data_ptr(), wt.data_ptr(), out.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, 32, h, w, cout
+    d.KH = d.KW = 3
+    d.stride_y = d.stride_x = d.pad_y = d.pad_x = 1
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = cv, cv * w, cv * w * h
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * w, cout * w * h
+    d.temperature, d.in_valid_c = 1.0, cv
+    L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2 ** -7, atol=2e-2)
+    assert np.linalg.norm(got - want) <= 4e-3 * np.linalg.norm(want)
+    # shapes no kernel reads that way are refused, not computed on memory that does not exist
+    d.KH = d.KW = 1
+    d.pad_y = d.pad_x = 0
+    assert lib.miseg_conv2d_fwd(C.byref(d), None) != 0
+    d.KH = d.KW = 3
+    d.pad_y = d.pad_x = 1
+    d.in_valid_c = 12
+    assert lib.miseg_conv2d_fwd(C.byref(d), None) != 0
+
+
 def test_prep_input_and_stem(env):
     """bn_data + ZeroPadding2D(3) + 7x7/2 stem conv via the channel-padded 7x1 form."""
     from oracle import ops_np
