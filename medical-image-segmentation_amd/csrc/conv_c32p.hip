@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
   dl.okc[0] = dl.c2[0] + 8 <= p.Cout;
   dl.okc[1] = dl.c2[1] + 8 <= p.Cout;
   dl.relu = p.act == MISEG_ACT_RELU;
-  const bool stats = p.stats != nullptr;
+  const bool head = p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID;
+  const bool stats = p.stats != nullptr && !head;
   float st[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) st[j] = 0.f;
@@ -209,13 +210,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
     patch_origin(tile, n, y0, x0);
     const int ox = x0 + lrow;
     const uint4 nores[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    static_for<2>([&](auto bc) __attribute__((always_inline)) {
-      constexpr int b = decltype(bc)::value;
-      const int oy = y0 + 2 * wave + b;
-      const bool okp = oy < p.Ho && ox < p.Wo;
-      const long long o_off = n * p.out_img_stride + (long long)oy * p.out_row_stride + (long long)ox * p.out_pix_stride;
-      direct_tile(p, dl, acc[b], okp, okp ? o_off : 0, 0, false, nores, nullptr, st, stats);
-    });
+    if (head) {
+      // softmax / sigmoid head (Cout <= 4, fp32 out): the lower half-wave's first four accumulators are
+      // couts 0..3 of the lane's pixel; bias, activation and collapse in registers, 4 * Cout bytes per lane
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int oy = y0 + 2 * wave + b;
+        if (lhalf == 0 && oy < p.Ho && ox < p.Wo) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = acc[b][j] * dl.sc[j] + dl.sh[j];
+          const long long o_off = n * p.out_img_stride + (long long)oy * p.out_row_stride + (long long)ox * p.out_pix_stride;
+          head_store(p, v, reinterpret_cast<float*>(p.out) + o_off,
+                     p.collapse_out ? p.collapse_out + (((long long)n * p.Ho + oy) * p.Wo + ox) * p.Cout : nullptr);
+        }
+      }
+    } else {
+      static_for<2>([&](auto bc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value;
+        const int oy = y0 + 2 * wave + b;
+        const bool okp = oy < p.Ho && ox < p.Wo;
+        const long long o_off = n * p.out_img_stride + (long long)oy * p.out_row_stride + (long long)ox * p.out_pix_stride;
+        direct_tile(p, dl, acc[b], okp, okp ? o_off : 0, 0, false, nores, nullptr, st, stats);
+      });
+    }
     CP_TICK(4);
 #ifdef MISEG_CP_PROFILE
     cp_t[6] += 1;
@@ -258,11 +276,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
   }
 }
 
-// The layers this kernel takes over from conv3x3_c32_kernel: bf16 output whose 8-channel groups
-// can be stored as 16 bytes, no residual, no second output.
+// The layers this kernel takes over from conv3x3_c32_kernel: bf16 output whose 8-channel groups can be
+// stored as 16 bytes, or the softmax / sigmoid head (fp32 out, Cout <= 4); no residual, no second output.
 bool conv_c32p_ok(const ConvParams& p) {
-  return p.vec_ok && p.out && p.out_dtype == MISEG_DT_BF16 && (p.Cout & 7) == 0 && !p.residual && !p.out2 &&
-         p.act != MISEG_ACT_SOFTMAX && p.act != MISEG_ACT_SIGMOID;
+  if (p.residual || p.out2 || !p.out) return false;
+  if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID)
+    return p.out_dtype == MISEG_DT_F32 && p.Cout <= 4 && !p.stats;
+  return p.vec_ok && p.out_dtype == MISEG_DT_BF16 && (p.Cout & 7) == 0;
 }
 
 hipError_t launch_conv_c32p(const ConvParams& p, hipStream_t s) {
