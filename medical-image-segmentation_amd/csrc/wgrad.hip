@@ -218,6 +218,148 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// All taps per block, for thin layers with any stride: Cin <= 32, Cout <= 64, 2..8 taps (the 7x7
+// stride-2 stem in its 7x1 form over 32-"channel" pixel windows).  The per-tap kernel above reads the
+// dY tile once per tap (seven times 2.5 GB for the stem at 16 x 1920 x 2560); here a K-step's dY tile
+// [64 pixels][64 couts] is staged once, next to the X tiles [64 pixels][32 channels] of every tap, and
+// wave (wm, wn) multiplies cout group wm with the taps [4 wn, 4 wn + 4).  Split-K over pixels, fp32
+// atomics at the end, as above.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad_alltaps_kernel(const WgradParams p) {
+  constexpr int YT = 64 * 128;            // dY tile bytes: 64 pixel rows of 128 B
+  constexpr int XT = 64 * 64;             // X tile bytes per tap: 64 pixel rows of 64 B
+  constexpr int STAGE = YT + 8 * XT;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kz = blockIdx.x;
+  const int ks_begin = kz * p.ksteps_per_split;
+  int ks_end = ks_begin + p.ksteps_per_split;
+  if (ks_end > p.ksteps_total) ks_end = p.ksteps_total;
+  const int HoWo = p.Ho * p.Wo;
+  const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(g_zero_line_wg);
+
+  // staged rows: dY instruction j covers rows (2 wave + j) * 8 + lane / 8 (8 chunks of 16 B per row), an X
+  // instruction covers rows wave * 16 + lane / 4 (4 chunks per row); both advance by 64 pixels per K-step
+  struct Row { int n, oy, ox, m; };
+  auto locate = [&](int row) {
+    Row r;
+    r.m = ks_begin * 64 + row;
+    const int mm = r.m < p.M ? r.m : 0;
+    r.n = mm / HoWo;
+    const int rem = mm - r.n * HoWo;
+    r.oy = rem / p.Wo;
+    r.ox = rem - r.oy * p.Wo;
+    return r;
+  };
+  auto advance = [&](Row& r) {
+    r.m += 64;
+    r.ox += 64;
+    while (r.ox >= p.Wo) {
+      r.ox -= p.Wo;
+      if (++r.oy == p.Ho) {
+        r.oy = 0;
+        ++r.n;
+      }
+    }
+  };
+  Row ry[2] = {locate((2 * wave) * 8 + (lane >> 3)), locate((2 * wave + 1) * 8 + (lane >> 3))};
+  Row rx = locate(wave * 16 + (lane >> 2));
+  int ych[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) ych[j] = wg_swz<64>((2 * wave + j) * 8 + (lane >> 3), lane & 7) * 8;
+  const int xch = (lane & 3) * 8;
+
+  auto issue = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* st = lds + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const Row& r = ry[j];
+      const bf16_t* src = (r.m < p.M && ych[j] < p.Cout)
+                              ? p.dy + r.n * p.dy_img + (long long)r.oy * p.dy_row + (long long)r.ox * p.dy_pix + ych[j]
+                              : zero_src;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + (2 * wave + j) * 1024), 16, 0, 0);
+    }
+    for (int tap = 0; tap < p.taps; ++tap) {
+      const int ky = tap / p.KW, kx = tap - ky * p.KW;
+      const int iy = rx.oy * p.stride_y - p.pad_y + ky, ix = rx.ox * p.stride_x - p.pad_x + kx;
+      const bool ok = rx.m < p.M && xch < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const bf16_t* src = ok ? p.x + rx.n * p.x_img + (long long)iy * p.x_row + (long long)ix * p.x_pix + xch : zero_src;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(st + YT + tap * XT + wave * 1024), 16,
+                                       0, 0);
+    }
+    advance(ry[0]);
+    advance(ry[1]);
+    advance(rx);
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposing reads: 16-lane group g takes a 4 (pixels) x 16 (channels) block, see the per-tap kernel
+  const int g = lane >> 4;
+  const int kgrp = 8 * (g >> 1) + ((lane & 15) >> 2);
+  const int cgrp = 16 * (g & 1) + 4 * (lane & 3);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto read2 = [&](const unsigned char* a0, const unsigned char* a1) __attribute__((always_inline)) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  const int tap0 = wn * 4;
+  const int ntap = p.taps - tap0 < 4 ? p.taps - tap0 : 4;      // may be <= 0: that wave only stages
+
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const unsigned char* yt = lds + buf * STAGE;
+    const unsigned char* xt = yt + YT + tap0 * XT;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int r0 = ks * 16 + kgrp, r1 = r0 + 4;
+      const int ycol = wm * 32 + cgrp;
+      const bf16x8 yf = read2(yt + r0 * 128 + wg_swz<64>(r0, ycol >> 3) * 16 + (ycol & 7) * 2,
+                              yt + r1 * 128 + wg_swz<64>(r1, ycol >> 3) * 16 + (ycol & 7) * 2);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < ntap) {
+          const bf16x8 xf = read2(xt + t * XT + r0 * 64 + cgrp * 2, xt + t * XT + r1 * 64 + cgrp * 2);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(yf, xf, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  if (ks_begin < ks_end) {
+    issue(0);
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+      const int it = ks - ks_begin;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (ks + 1 < ks_end) issue((it + 1) & 1);
+      compute(it & 1);
+    }
+  }
+
+  const int lcol = lane & 31, lhalf = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t >= ntap) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+      if (co < p.Cout && lcol < p.Cin)
+        atomicAdd(p.dw + ((long long)co * p.taps + tap0 + t) * p.Cin + lcol, acc[t][r]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Halo-resident weight gradient for stride-1 convolutions with small filters (3x3, the 2x2 phases
 // of Conv2DTranspose, 1x1).  The per-tap kernel above re-reads both operand tiles for every tap;
 // here a block keeps the X halo tile and the dY tile of an 8x32 pixel block in LDS and a wave
@@ -482,6 +624,17 @@ int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream) {
     if (d->KH == 3) launch_halo_wgrad<3, 3>(p, stream);
     else if (d->KH == 2) launch_halo_wgrad<2, 2>(p, stream);
     else launch_halo_wgrad<1, 1>(p, stream);
+    MISEG_CHECK_HIP(hipGetLastError());
+    return MISEG_OK;
+  }
+  if (d->tile_hint == 0 && d->Cin <= 32 && d->Cout <= 64 && p.taps >= 2 && p.taps <= 8) {
+    // ~2 blocks per CU, each with at least a few K-steps between its staging and its flush
+    long long want = 512;
+    if (want > p.ksteps_total / 4) want = p.ksteps_total / 4;
+    if (want < 1) want = 1;
+    p.ksteps_per_split = (int)((p.ksteps_total + want - 1) / want);
+    p.ksplit = (p.ksteps_total + p.ksteps_per_split - 1) / p.ksteps_per_split;
+    hipLaunchKernelGGL(wgrad_alltaps_kernel, dim3((unsigned)p.ksplit), dim3(256), 0, stream, p);
     MISEG_CHECK_HIP(hipGetLastError());
     return MISEG_OK;
   }

@@ -767,7 +767,9 @@ class Trainer:
         d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
         d.dy_pix, d.dy_row, d.dy_img = dy_strides
         halo = sx == 1 and sy == 1 and kh == kw and kh <= 3 and cin % 32 == 0 and 0 <= py < kh and 0 <= px < kw
-        self.lib.note("wgrad_halo_kernel" if halo else "conv_wgrad_kernel", d.N * ho * wo * cout * kh * kw * cin,
+        thin = not halo and cin <= 32 and cout <= 64 and 2 <= kh * kw <= 8
+        self.lib.note("wgrad_halo_kernel" if halo else ("wgrad_alltaps_kernel" if thin else "conv_wgrad_kernel"),
+                      d.N * ho * wo * cout * kh * kw * cin,
                       d.N * d.H * d.W * cin * 2 + d.N * ho * wo * cout * 2 + cout * kh * kw * cin * 4)
         if self.side is None or not side:
             L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.stream()))

@@ -90,6 +90,43 @@ def test_wgrad(env, case, hint):
     np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("hint", [0, 1])
+@pytest.mark.parametrize("case", [
+    # n, h, w, cin, cout, kh, kw, sy, sx, py, px
+    (2, 38, 24, 32, 64, 7, 1, 2, 1, 3, 0),     # the stem's form: 7x1 taps, stride 2 down the rows
+    (1, 70, 40, 32, 64, 7, 1, 2, 1, 0, 0),     # several K-steps per block
+    (1, 16, 20, 32, 32, 2, 2, 2, 2, 0, 0),     # four taps
+    (3, 9, 11, 16, 24, 3, 1, 1, 1, 1, 0),      # ragged channels, three taps, a tap range with no wave work
+    (1, 12, 16, 32, 64, 2, 4, 1, 2, 1, 1),     # eight taps
+])
+def test_wgrad_thin_layers_all_taps(env, case, hint):
+    """Cin <= 32, Cout <= 64, 2..8 taps: hint 0 takes the kernel that stages dY once for all taps, hint 1 the
+    per-tap kernel; both against torch autograd."""
+    L, lib, dev = env
+    n, h, w, cin, cout, kh, kw, sy, sx, py, px = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    ho = (h + 2 * py - kh) // sy + 1
+    wo = (w + 2 * px - kw) // sx + 1
+    dy = bf16_round(rng.normal(0, 1, (n, ho, wo, cout)))
+    wt = torch.zeros((cout, cin, kh, kw), requires_grad=True)
+    out = F.conv2d(torch.from_numpy(x).permute(0, 3, 1, 2), wt, stride=(sy, sx), padding=(py, px))
+    out.backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    want = wt.grad.permute(0, 2, 3, 1).numpy()          # [Cout][KH][KW][Cin]
+    xd, dyd = dbf(x, dev), dbf(dy, dev)
+    dw = torch.zeros((cout, kh, kw, cin), dtype=torch.float32, device=dev)
+    d = L.WgradDesc()
+    d.x, d.dy, d.dw = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, ho, wo, cout
+    d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
+    d.x_pix, d.x_row, d.x_img = cin, cin * w, cin * w * h
+    d.dy_pix, d.dy_row, d.dy_img = cout, cout * wo, cout * wo * ho
+    d.tile_hint = hint
+    L.check(lib.miseg_conv2d_wgrad(C.byref(d), None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+
+
 @pytest.mark.parametrize("hint", [1, 2])
 def test_wgrad_transpose_conv_phase_views(env, hint):
     """Weight gradient of Conv2DTranspose(4,2,'same'): one call per phase with dy viewed on the
