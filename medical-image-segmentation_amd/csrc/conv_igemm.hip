@@ -781,6 +781,8 @@ bool conv_c32p_ok(const ConvParams& p);
 hipError_t launch_conv_c32p(const ConvParams& p, hipStream_t s);
 bool conv_stem7_ok(const ConvParams& p);
 hipError_t launch_conv_stem7(ConvParams p, hipStream_t s);
+bool conv_pw_pro_ok(const ConvParams& p);
+hipError_t launch_conv_pw_pro(ConvParams p, hipStream_t s);
 struct KernelChoice {
   KernelKind kind;
   int cfg;  // 1..7 index into kCfgs; 8..10 halo variants
@@ -846,6 +848,10 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
   }
   if (kc.kind == K_C32 && persist && conv_c32p_ok(pp)) {
     snprintf(buf, len, "conv3x3_c32p_kernel");
+    return;
+  }
+  if (kc.kind == K_REG_PRO && (d->tile_hint & 15) == 0 && conv_pw_pro_ok(pp)) {
+    snprintf(buf, len, "conv_pw_pro_kernel");
     return;
   }
   static const char* shapes[] = {"2, 2, 2, 2", "4, 1, 2, 2", "4, 1, 2, 1", "2, 2, 1, 1",
@@ -985,6 +991,14 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   hipError_t e;
   if ((d->tile_hint & 15) == 0 && !(d->tile_hint & MISEG_TILE_NO_PERSIST) && conv_stem7_ok(p)) {
     e = launch_conv_stem7(p, stream);
+    if (e != hipSuccess) {
+      set_error("conv launch failed: %s", hipGetErrorString(e));
+      return MISEG_E_HIP;
+    }
+    return MISEG_OK;
+  }
+  if (kc.kind == K_REG_PRO && (d->tile_hint & 15) == 0 && conv_pw_pro_ok(p)) {
+    e = launch_conv_pw_pro(p, stream);
     if (e != hipSuccess) {
       set_error("conv launch failed: %s", hipGetErrorString(e));
       return MISEG_E_HIP;

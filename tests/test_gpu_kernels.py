@@ -358,6 +358,53 @@ def test_conv_prologue(env, k, pad):
     np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3 * np.abs(want).max())
 
 
+@pytest.mark.parametrize("shape", [(1, 9, 11, 96, 128), (2, 16, 24, 256, 128), (1, 13, 17, 64, 64),
+                                   (1, 8, 40, 1280, 640), (1, 20, 20, 160, 192), (3, 7, 9, 512, 72)])
+@pytest.mark.parametrize("epilogue", [False, True])
+def test_conv_pointwise_prologue_16bit(env, shape, epilogue):
+    """1x1 convolution with BatchNorm+ReLU on its operand and 16-bit output (DenseNet's transition layers):
+    the LDS-DMA kernel that applies the prologue to the fragments (hint 0) against the register-staged generic
+    kernel (hint 1) and the oracle; ragged pixel and cout tiles, input and output as channel slices."""
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(29)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    wt = bf16_round(rng.normal(0, 1.0 / np.sqrt(cin), (1, 1, cin, cout)))
+    s = rng.uniform(0.5, 1.5, cin).astype(np.float32)
+    t = rng.normal(0.3, 0.5, cin).astype(np.float32)
+    es = rng.uniform(0.5, 1.5, cout).astype(np.float32) if epilogue else None
+    et = rng.normal(0, 0.3, cout).astype(np.float32) if epilogue else None
+    act = 1 if epilogue else 0
+    outs = []
+    for hint in (0, 1):
+        got, _ = run_conv(env, x, wt, 1, 0, scale=es, shift=et, act=act, in_scale=s, in_shift=t, tile_hint=hint,
+                          in_extra_c=32, out_extra_c=32)
+        outs.append(got)
+    want = ref_conv(x, wt, 1, 0, in_scale=s, in_shift=t)
+    if epilogue:
+        want = np.maximum(want * es + et, 0)
+    # one rounding of the stored result, and (fp16 storage) the prologue in packed fp16 arithmetic
+    tol = 2 ** -7 if STORAGE["fmt"] == 0 else 2 ** -8
+    np.testing.assert_allclose(outs[0], want, rtol=tol, atol=tol * np.abs(want).max())
+    assert np.linalg.norm(outs[0] - want) <= 0.6 * tol * np.linalg.norm(want)
+    np.testing.assert_allclose(outs[0], outs[1], rtol=tol, atol=tol * np.abs(want).max())
+    L, lib, dev = env
+    # the dispatch really took the new kernel for these shapes
+    d = new_desc(L)
+    xin = torch.zeros((n, h, w, cin), dtype=h16(), device=dev)
+    wd = torch.zeros((cout, cin), dtype=h16(), device=dev)
+    o = torch.zeros((n, h, w, cout), dtype=h16(), device=dev)
+    sd, td = dev_f32(s, dev), dev_f32(t, dev)
+    d.inp, d.weight, d.out, d.in_scale, d.in_shift = xin.data_ptr(), wd.data_ptr(), o.data_ptr(), sd.data_ptr(), td.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, h, w, cout
+    d.KH = d.KW = d.stride_y = d.stride_x = 1
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin, cin * w, cin * w * h
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * w, cout * w * h
+    d.temperature = 1.0
+    buf = C.create_string_buffer(128)
+    L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+    assert buf.value.decode() == "conv_pw_pro_kernel", buf.value
+
+
 @pytest.mark.parametrize("shape", [(2, 6, 7, 64, 32), (1, 9, 35, 128, 64), (1, 8, 32, 64, 160),
                                    (2, 5, 5, 32, 16), (1, 17, 40, 192, 128)])
 @pytest.mark.parametrize("hint", [0, 11, 12, 15, 16, 32])
