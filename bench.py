@@ -137,7 +137,9 @@ def training_leg(args, dev, rank, world, dist, h, w):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
-    roof = train_roofline(tr.profile_step(x, gt), 1e3 * elapsed / args.train_steps,
+    # every rank runs the profiled step: it all-reduces its gradient buckets like any other step
+    prof = tr.profile_step(x, gt)
+    roof = train_roofline(prof, 1e3 * elapsed / args.train_steps,
                           (args.train_batch, h, w, args.train_encoder, args.decoder + "-train")) if rank == 0 else None
     del tr, x, gt
     torch.cuda.empty_cache()
