@@ -82,7 +82,7 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, out_dir):
+def _dp_worker(rank, world, port, out_dir, enc="resnet18", dec="U-Net", hw=(64, 96), bucket_mb=8):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -92,10 +92,10 @@ def _dp_worker(rank, world, port, out_dir):
     import miseg_amd  # noqa: F401
     from miseg_amd import netspec, trainer
     from oracle import nets
-    w = nets.init_weights(nets.build_spec("resnet18", "U-Net", 3), 0, True)
-    g = netspec.build_graph("resnet18", "U-Net", (64, 96, 3), 3, "softmax", None)
-    x, y = _data(2, 64, 96, seed=4)
-    tr = trainer.Trainer(g, w, 1, world_size=world, bucket_mb=8)
+    w = nets.init_weights(nets.build_spec(enc, dec, 3), 0, True)
+    g = netspec.build_graph(enc, dec, (hw[0], hw[1], 3), 3, "softmax", None)
+    x, y = _data(2, hw[0], hw[1], seed=4)
+    tr = trainer.Trainer(g, w, 1, world_size=world, bucket_mb=bucket_mb)
     xd = torch.from_numpy(x[rank:rank + 1]).cuda()
     yd = torch.from_numpy(y[rank:rank + 1]).cuda()
     tr.forward(xd)
@@ -107,7 +107,13 @@ def _dp_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_data_parallel_gradients_two_ranks_one_gpu(pkg, tmp_path):
+# the DenseNet-169 FPN is the data-parallel training configuration of the reference's README; its backward
+# writes several layers' gradients from one fused call (head, final_stage, the folded finest level), so the
+# buckets must not leave before the last of them.  2 MB buckets: a dozen of them for these networks.
+@pytest.mark.parametrize("enc,dec,hw,bucket_mb", [("resnet18", "U-Net", (64, 96), 8),
+                                                  ("densenet169", "FPN", (64, 64), 2),
+                                                  ("densenet121", "Linknet", (64, 64), 2)])
+def test_data_parallel_gradients_two_ranks_one_gpu(pkg, tmp_path, enc, dec, hw, bucket_mb):
     """Two ranks (sharing the one GPU of the test box, gloo staging through the host) each take
     one image; the all-reduced gradient equals the mean of the two single-rank gradients."""
     import torch
@@ -115,15 +121,15 @@ def test_data_parallel_gradients_two_ranks_one_gpu(pkg, tmp_path):
     from miseg_amd import netspec, trainer
     from oracle import nets
     world = 2
-    mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_dp_worker, args=(world, _free_port(), str(tmp_path), enc, dec, hw, bucket_mb), nprocs=world, join=True)
     r0 = torch.load(os.path.join(str(tmp_path), "dp0.pt"))
     r1 = torch.load(os.path.join(str(tmp_path), "dp1.pt"))
     assert torch.equal(r0["G"], r1["G"])
     assert len(r0["buckets"]) >= 3                          # several buckets, not one per layer
     assert sum(hi - lo for lo, hi in r0["buckets"]) == r0["G"].numel()
-    w = nets.init_weights(nets.build_spec("resnet18", "U-Net", 3), 0, True)
-    g = netspec.build_graph("resnet18", "U-Net", (64, 96, 3), 3, "softmax", None)
-    x, y = _data(2, 64, 96, seed=4)
+    w = nets.init_weights(nets.build_spec(enc, dec, 3), 0, True)
+    g = netspec.build_graph(enc, dec, (hw[0], hw[1], 3), 3, "softmax", None)
+    x, y = _data(2, hw[0], hw[1], seed=4)
     tr = trainer.Trainer(g, w, 1)
     total = None
     for r in range(world):
