@@ -131,17 +131,33 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, long long co
 }
 
 // The same from the replicated sums a convolution's epilogue gathered: stats[r][2][stride], r < replicas.
-__global__ void bn_finalize_replicas_kernel(const double* __restrict__ stats, int replicas, int stride,
-                                            long long count, int C, const float* __restrict__ gamma,
-                                            const float* __restrict__ beta, float* moving_mean, float* moving_var,
-                                            float momentum, float eps, float* mean, float* var, float* scale,
-                                            float* shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// Block = 64 channels x FIN_RG replica groups: a thread adds every FIN_RG-th replica of its channel (its
+// loads are independent and in flight together; one thread walking all replicas waited for 2 x replicas
+// loads one after the other, 17 us for 32 replicas), the groups meet in LDS.
+constexpr int FIN_RG = 8;
+__global__ __launch_bounds__(64 * FIN_RG) void bn_finalize_replicas_kernel(
+    const double* __restrict__ stats, int replicas, int stride, long long count, int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* moving_mean, float* moving_var,
+    float momentum, float eps, float* mean, float* var, float* scale, float* shift) {
+  __shared__ double part[FIN_RG][2][64];
+  const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < replicas; ++r) {
-    s1 += stats[((long long)r * 2 + 0) * stride + c];
-    s2 += stats[((long long)r * 2 + 1) * stride + c];
+  if (c < C) {
+#pragma unroll 4
+    for (int r = rg; r < replicas; r += FIN_RG) {
+      s1 += stats[((long long)r * 2 + 0) * stride + c];
+      s2 += stats[((long long)r * 2 + 1) * stride + c];
+    }
+  }
+  part[rg][0][lc] = s1;
+  part[rg][1][lc] = s2;
+  __syncthreads();
+  if (rg != 0 || c >= C) return;
+#pragma unroll
+  for (int g = 1; g < FIN_RG; ++g) {
+    s1 += part[g][0][lc];
+    s2 += part[g][1][lc];
   }
   const double m = s1 / (double)count;
   double v = s2 / (double)count - m * m;
@@ -165,7 +181,7 @@ int launch_bn_finalize(const double* stats, int replicas, int stride, long long 
   MISEG_CHECK_ARG(stats && beta && mean && var && scale && shift, "bn_finalize: null pointer");
   MISEG_CHECK_ARG(pixels > 0 && C > 0 && replicas > 1 && stride >= C, "bn_finalize: bad extents");
   MISEG_CHECK_ARG((mm == nullptr) == (mv == nullptr), "bn_finalize: moving stats go together");
-  hipLaunchKernelGGL(bn_finalize_replicas_kernel, dim3((C + 63) / 64), dim3(64), 0, s, stats, replicas, stride,
+  hipLaunchKernelGGL(bn_finalize_replicas_kernel, dim3((C + 63) / 64), dim3(64 * FIN_RG), 0, s, stats, replicas, stride,
                      pixels, C, gamma, beta, mm, mv, momentum, eps, mean, var, scale, shift);
   MISEG_CHECK_HIP(hipGetLastError());
   return MISEG_OK;
