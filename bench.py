@@ -104,7 +104,7 @@ def pmc_traffic(kernel, batch, h, w, encoder, decoder):
     return sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in fam) / sum(v["dispatches"] for v in fam)
 
 
-def training_leg(args, dev, rank, world, dist, h, w):
+def training_leg(args, dev, rank, world, dist, h, w, augment=False):
     """Second headline configuration: ResNet-18 U-Net training steps (forward on batch statistics,
     cce+Dice loss, backward, bucketed gradient all-reduce over RCCL overlapped with the backward
     pass, Adam) on a fixed synthetic batch per GPU -- the loop behind `model.fit`,
@@ -118,15 +118,27 @@ def training_leg(args, dev, rank, world, dist, h, w):
     lab = torch.randint(0, args.classes, (args.train_batch, h, w), device=dev, generator=gen)
     gt = torch.nn.functional.one_hot(lab, args.classes).float()
     del lab
+    if augment:
+        # the reference's augment_dataset (utils/data.py:240-295: flips, brightness, contrast, hue, saturation,
+        # drawn per image) on the device, inside the timed step
+        from miseg_amd import imageops
+        arng = np.random.default_rng(4321 + rank)
+
+        def one_step():
+            xa, ga = imageops.augment(x, gt, imageops.random_augment_params(args.train_batch, arng))
+            tr.train_step(xa, ga)
+    else:
+        def one_step():
+            tr.train_step(x, gt)
     for _ in range(args.train_warmup):
-        tr.train_step(x, gt)
+        one_step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
-        tr.train_step(x, gt)
+        one_step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -151,8 +163,10 @@ def training_leg(args, dev, rank, world, dist, h, w):
             "warmup": args.train_warmup, "scaling": "weak",
             "dtype": "bf16 activations/gradients, fp32 accumulation and master weights",
             "config": {"workload": "%s %s training %dx%dx3, %d classes, cce+Dice loss, Adam, batch %d "
-                                   "per GPU per step" % (args.train_encoder, args.decoder, h, w,
-                                                         args.classes, args.train_batch),
+                                   "per GPU per step%s" % (args.train_encoder, args.decoder, h, w,
+                                                           args.classes, args.train_batch,
+                                                           ", on-device augmentation (flips, brightness, contrast, "
+                                                           "hue, saturation) inside the step" if augment else ""),
                        "parallelism": "data parallel, bucketed RCCL all-reduce overlapped with backward"
                        if world > 1 else "single GPU"},
             "peak_hbm_gib": peak, "roofline": roof}
@@ -384,7 +398,7 @@ def main():
             # BASELINE.json config 5: DenseNet-169 FPN training (Dice loss, data parallel), 4 images per GPU
             a5 = argparse.Namespace(**vars(args))
             a5.train_encoder, a5.decoder, a5.train_batch, a5.train_steps, a5.train_warmup = "densenet169", "FPN", 4, 3, 1
-            train5 = training_leg(a5, dev, rank, world, dist, h, w)
+            train5 = training_leg(a5, dev, rank, world, dist, h, w, augment=True)
 
     result = None
     if rank == 0:

@@ -783,6 +783,13 @@ bool conv_stem7_ok(const ConvParams& p);
 hipError_t launch_conv_stem7(ConvParams p, hipStream_t s);
 bool conv_pw_pro_ok(const ConvParams& p);
 hipError_t launch_conv_pw_pro(ConvParams p, hipStream_t s);
+bool conv_pw_thin_ok(const ConvParams& p);
+hipError_t launch_conv_pw_thin(ConvParams p, hipStream_t s);
+// short-contraction 1x1 layers go to the persistent point-wise kernel (MISEG_NO_PW_THIN keeps them on the tiles)
+static bool pw_thin_wanted(const miseg_conv_desc* d, const ConvParams& p, KernelKind kind) {
+  static const bool off = getenv("MISEG_NO_PW_THIN") != nullptr;
+  return !off && kind == K_DMA && (d->tile_hint & 15) == 0 && conv_pw_thin_ok(p);
+}
 struct KernelChoice {
   KernelKind kind;
   int cfg;  // 1..7 index into kCfgs; 8..10 halo variants
@@ -852,6 +859,10 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
   }
   if (kc.kind == K_REG_PRO && (d->tile_hint & 15) == 0 && conv_pw_pro_ok(pp)) {
     snprintf(buf, len, "conv_pw_pro_kernel");
+    return;
+  }
+  if (pw_thin_wanted(d, pp, kc.kind)) {
+    snprintf(buf, len, "conv_pw_thin_kernel<%d>", d->Cin / 16);
     return;
   }
   static const char* shapes[] = {"2, 2, 2, 2", "4, 1, 2, 2", "4, 1, 2, 1", "2, 2, 1, 1",
@@ -999,6 +1010,14 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   }
   if (kc.kind == K_REG_PRO && (d->tile_hint & 15) == 0 && conv_pw_pro_ok(p)) {
     e = launch_conv_pw_pro(p, stream);
+    if (e != hipSuccess) {
+      set_error("conv launch failed: %s", hipGetErrorString(e));
+      return MISEG_E_HIP;
+    }
+    return MISEG_OK;
+  }
+  if (pw_thin_wanted(d, p, kc.kind)) {
+    e = launch_conv_pw_thin(p, stream);
     if (e != hipSuccess) {
       set_error("conv launch failed: %s", hipGetErrorString(e));
       return MISEG_E_HIP;

@@ -14,6 +14,10 @@ ap.add_argument("--transposed", action="store_true")
 ap.add_argument("--relu", action="store_true")
 ap.add_argument("--softmax", action="store_true")
 ap.add_argument("--f32out", action="store_true")
+ap.add_argument("--residual", action="store_true", help="16-bit residual added before the activation")
+ap.add_argument("--res-up", action="store_true", help="residual at half resolution, read at (y >> 1, x >> 1)")
+ap.add_argument("--out2", action="store_true", help="second (linear) 16-bit output")
+ap.add_argument("--res-after", action="store_true", help="... after the activation (LinkNet's skip additions)")
 a = ap.parse_args()
 n, h, w, cin, cout, k = a.dims[:6]
 stride = a.dims[6] if len(a.dims) > 6 else 1
@@ -51,6 +55,24 @@ if a.softmax:
     d.act = L.ACT_SOFTMAX
     d.collapse_out = mask.data_ptr()
     d.collapse_value = 127
+if a.out2:
+    out2 = torch.zeros((n, oh, ow, cout), dtype=torch.bfloat16, device=dev)
+    d.out2 = out2.data_ptr()
+    d.out2_pix_stride, d.out2_row_stride, d.out2_img_stride = cout, cout * ow, cout * ow * oh
+    d.scale2, d.shift2 = sc.data_ptr(), sh.data_ptr()
+    d.out2_linear = 1
+if a.res_up:
+    res = torch.randn((n, oh // 2, ow // 2, cout), generator=g).to(torch.bfloat16).to(dev)
+    d.residual = res.data_ptr()
+    d.res_pix_stride, d.res_row_stride, d.res_img_stride = cout, cout * (ow // 2), cout * (ow // 2) * (oh // 2)
+    d.res_dtype = L.DT_BF16
+    d.res_upsample_shift = 1
+if a.residual or a.res_after:
+    res = torch.randn((n, oh, ow, cout), generator=g).to(torch.bfloat16).to(dev)
+    d.residual = res.data_ptr()
+    d.res_pix_stride, d.res_row_stride, d.res_img_stride = cout, cout * ow, cout * ow * oh
+    d.res_dtype = L.DT_BF16
+    d.res_after_act = 1 if a.res_after else 0
 d.transposed = 1 if a.transposed else 0
 d.temperature = 1.0
 d.tile_hint = a.hint

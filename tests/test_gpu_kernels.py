@@ -234,6 +234,66 @@ def test_conv_residual_upsampled(env, shape, res_f32):
         np.testing.assert_allclose(got, want, rtol=tol, atol=tol * np.abs(want).max())
 
 
+@pytest.mark.parametrize("shape", [(2, 11, 37, 64, 40), (1, 16, 24, 128, 256), (3, 9, 21, 192, 200), (1, 13, 50, 256, 640),
+                                   (2, 30, 34, 64, 128)])
+@pytest.mark.parametrize("mode", ["relu", "res", "res_after", "res_up", "out2", "out2_linear"])
+def test_conv_pointwise_short_contraction(env, shape, mode):
+    """1x1 layers with Cin in {64, 128, 192, 256} and 16-bit output run on the persistent point-wise kernel
+    (weights of a 128-cout tile in LDS, pixel fragments straight from memory): LinkNet's decoder 1x1 layers with
+    their skip additions, FPN's lateral layers with the up-sampled addend, both as channel slices of wider
+    buffers (segmentation_models DecoderBlock / FPNBlock, /root/reference utils/model.py:188-211)."""
+    L, lib, dev = env
+    n, h, w, cin, cout = shape
+    rng = np.random.default_rng(cin * 7 + cout + len(mode))
+    x = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    wt = bf16_round(rng.normal(0, 0.1, (1, 1, cin, cout)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.5, cout).astype(np.float32)
+    base = ref_conv(x, wt, 1, 0) * sc + sh
+    kw = dict(scale=sc, shift=sh, in_extra_c=8, out_extra_c=16)
+    want2 = None
+    if mode == "relu":
+        want = np.maximum(base, 0)
+        kw.update(act=1)
+    elif mode in ("res", "res_after"):
+        res = bf16_round(rng.normal(0, 1, (n, h, w, cout)))
+        want = np.maximum(base + res, 0) if mode == "res" else np.maximum(base, 0) + res
+        kw.update(act=1, residual=res, res_f32=False, res_after=mode == "res_after")
+    elif mode == "res_up":
+        if h % 2 or w % 2:
+            h2, w2 = (h + 1) // 2, (w + 1) // 2
+        else:
+            h2, w2 = h // 2, w // 2
+        res = bf16_round(rng.normal(0, 1, (n, h2, w2, cout)))
+        want = base + np.repeat(np.repeat(res, 2, axis=1), 2, axis=2)[:, :h, :w]
+        kw.update(residual=res, res_f32=False, res_shift=1)
+    else:
+        s2 = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        t2 = rng.normal(0, 0.5, cout).astype(np.float32)
+        want = base
+        want2 = base * s2 + t2 if mode == "out2_linear" else np.maximum(base * s2 + t2, 0)
+        kw.update(scale2=s2, shift2=t2, out2_linear=mode == "out2_linear")
+    got, got2 = run_conv(env, x, wt, 1, 0, **kw)
+    np.testing.assert_allclose(got, want, rtol=1e-2, atol=1e-2 * np.abs(want).max())
+    if want2 is not None:
+        np.testing.assert_allclose(got2, want2, rtol=1e-2, atol=1e-2 * np.abs(want2).max())
+    # the tiled kernels (any tile hint) give the same values up to the order of the fp32 sums
+    alt, alt2 = run_conv(env, x, wt, 1, 0, tile_hint=1, **kw)
+    np.testing.assert_allclose(got, alt, rtol=1e-2, atol=1e-2 * np.abs(want).max())
+    # and the layer did run on the point-wise kernel
+    d = new_desc(L)
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, h, w, cout
+    d.KH = d.KW = d.stride_y = d.stride_x = 1
+    keep = torch.zeros(64, dtype=torch.float32, device=dev)
+    d.inp = d.weight = d.out = keep.data_ptr()
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin + 8, (cin + 8) * w, (cin + 8) * w * h
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout + 16, (cout + 16) * w, (cout + 16) * w * h
+    d.out_dtype = L.DT_BF16
+    buf = C.create_string_buffer(128)
+    L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+    assert buf.value.decode().startswith("conv_pw_thin_kernel<%d>" % (cin // 16)), buf.value
+
+
 def test_conv_epilogues(env):
     rng = np.random.default_rng(7)
     n, h, w, cin, cout = 2, 10, 12, 64, 64
