@@ -77,10 +77,10 @@ def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
 
 PMC_FILES = {
     # (images per plan, H, W, encoder, decoder) the counter passes were collected on -> reduced file
-    (4, 1920, 2560, "resnet34", "U-Net"): "r02_c_pmc_traffic.json",
-    (8, 1920, 2560, "densenet169", "Linknet"): "r02_c_pmc_traffic_d169_linknet.json",
-    (4, 1920, 2560, "densenet169", "FPN"): "r02_c_pmc_traffic_d169_fpn.json",
-    (16, 1920, 2560, "resnet18", "U-Net-train"): "r02_c_pmc_traffic_train_r18_unet.json",
+    (4, 1920, 2560, "resnet34", "U-Net"): "r02_d_pmc_traffic.json",
+    (8, 1920, 2560, "densenet169", "Linknet"): "r02_d_pmc_traffic_d169_linknet.json",
+    (4, 1920, 2560, "densenet169", "FPN"): "r02_d_pmc_traffic_d169_fpn.json",
+    (16, 1920, 2560, "resnet18", "U-Net-train"): "r02_d_pmc_traffic_train_r18_unet.json",
 }
 
 
@@ -473,7 +473,7 @@ def main():
                 "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": pmc_traffic(dom_name, args.batch, h, w, args.encoder, args.decoder),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes), "
-                                "from the committed PMC passes profiles/r02_c_pmc_*.csv",
+                                "from the committed PMC passes profiles/r02_d_pmc_*.csv",
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                 "all_conv_launches": {
                     "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,

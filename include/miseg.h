@@ -232,6 +232,38 @@ typedef struct miseg_linknet_tail_desc {
 int miseg_linknet_tail_fwd(const miseg_linknet_tail_desc* d, void* stream);
 
 /*
+ * A whole LinkNet decoder block whose skip tensor has 64 channels as one kernel (segmentation_models
+ * DecoderBlock `decoder_stage3` of the networks the reference builds at utils/model.py:188-198): `a`: Conv2D
+ * 1x1 cin -> m = cin / 4, `b`: Conv2DTranspose(4, 2, 'same') m -> m, `c`: Conv2D 1x1 m -> 64, each with
+ * BatchNorm + ReLU (folded into scale/shift vectors), then Add([c, skip]); cin = 64 (ResNet encoders) or 128
+ * (DenseNet encoders).  The two m-channel tensors stay on chip.  Same values as the three miseg_conv2d_fwd
+ * calls (the last with res_after_act) up to the order of the fp32 sums.
+ *   in  : 16-bit [N][H][W][>= cin channels] (strides in elements)
+ *   wa  : [m][cin]; wb: [4][m][2][2][m] (phase, cout, dy, dx, cin) as in miseg_linknet_tail_desc;
+ *   wc  : [64][32] (cout, cin; cin >= m zero)
+ *   sa, ta, sb, tb: m floats each; sc, tc: 64 floats
+ *   skip, out: 16-bit [N][2H][2W][>= 64 channels] (strides in elements, multiples of 4)
+ */
+typedef struct miseg_linknet_block_desc {
+  const void* in;
+  const void *wa, *wb, *wc;
+  const float *sa, *ta, *sb, *tb, *sc, *tc;
+  const void* skip;
+  void* out;
+  int32_t N, H, W;
+  int32_t in_pix_stride, in_row_stride;
+  int64_t in_img_stride;
+  int32_t skip_pix_stride, skip_row_stride;
+  int64_t skip_img_stride;
+  int32_t out_pix_stride, out_row_stride;
+  int64_t out_img_stride;
+  int32_t fmt; /* MISEG_FMT_* of in, the weights, skip and out */
+  int32_t cin; /* 64 or 128 */
+} miseg_linknet_block_desc;
+
+int miseg_linknet_block_fwd(const miseg_linknet_block_desc* d, void* stream);
+
+/*
  * The end of the FPN the reference builds at utils/model.py:200-211 as one kernel:
  * `final_upsampling` (UpSampling2D(2, interpolation='bilinear'): half-pixel centres, clamped
  * edges) + `head_conv` (Conv2D 3x3 128 -> classes <= 4 with bias, zero padding) + softmax /
@@ -626,6 +658,7 @@ int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d);
 int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, const miseg_conv_desc* head);
 int miseg_plan_add_dense_layer(miseg_plan* p, const miseg_conv_desc* c1, const miseg_conv_desc* c2);
 int miseg_plan_add_linknet_tail(miseg_plan* p, const miseg_linknet_tail_desc* d);
+int miseg_plan_add_linknet_block(miseg_plan* p, const miseg_linknet_block_desc* d);
 int miseg_plan_add_fpn_head(miseg_plan* p, const miseg_fpn_head_desc* d);
 int miseg_plan_add_prep_input(miseg_plan* p, const float* in, void* out, const float* scale,
                               const float* shift, int32_t N, int32_t H, int32_t W);

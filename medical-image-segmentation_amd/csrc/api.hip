@@ -72,12 +72,13 @@ namespace miseg_f16 {
 namespace miseg {
 
 enum OpKind { OP_CONV, OP_PREP, OP_MAXPOOL, OP_AVGPOOL, OP_UPNEAR, OP_UPBIL, OP_SSR, OP_CONV_HEAD, OP_DENSE, OP_LTAIL, OP_FPNHEAD,
-              OP_MAXPOOL2, OP_IM2COL, OP_HEADGATHER };
+              OP_MAXPOOL2, OP_IM2COL, OP_HEADGATHER, OP_LBLOCK };
 
 struct Op {
   OpKind kind;
   miseg_conv_desc conv;
   miseg_linknet_tail_desc tail;   // OP_LTAIL
+  miseg_linknet_block_desc block; // OP_LBLOCK
   miseg_fpn_head_desc fhead;      // OP_FPNHEAD
   miseg_conv_desc conv2;   // OP_CONV_HEAD: the head convolution; OP_DENSE: the 3x3 convolution
   const void* in;
@@ -98,6 +99,7 @@ static int run_op_f16(const Op& o, hipStream_t s) {
     case OP_CONV_HEAD: return F::launch_conv_c32_head(&o.conv, &o.conv2, s);
     case OP_DENSE: return F::launch_dense_layer(&o.conv, &o.conv2, s);
     case OP_LTAIL: return F::launch_linknet_tail(&o.tail, s);
+    case OP_LBLOCK: return F::launch_linknet_block(&o.block, s);
     case OP_FPNHEAD: return F::launch_fpn_head(&o.fhead, s);
     case OP_PREP: return F::launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
     case OP_MAXPOOL:
@@ -126,6 +128,7 @@ static int run_op(const Op& o, hipStream_t s, int fmt) {
     case OP_CONV_HEAD: return launch_conv_c32_head(&o.conv, &o.conv2, s);
     case OP_DENSE: return launch_dense_layer(&o.conv, &o.conv2, s);
     case OP_LTAIL: return launch_linknet_tail(&o.tail, s);
+    case OP_LBLOCK: return launch_linknet_block(&o.block, s);
     case OP_FPNHEAD: return launch_fpn_head(&o.fhead, s);
     case OP_PREP: return launch_prep_input((const float*)o.in, o.out, o.scale, o.shift, o.N, o.H, o.W, s);
     case OP_MAXPOOL:
@@ -218,6 +221,12 @@ int miseg_linknet_tail_fwd(const miseg_linknet_tail_desc* d, void* stream) {
   MISEG_CHECK_FMT(d->fmt);
   if (d->fmt == MISEG_FMT_F16) return miseg_f16::launch_linknet_tail(d, (hipStream_t)stream);
   return launch_linknet_tail(d, (hipStream_t)stream);
+}
+
+int miseg_linknet_block_fwd(const miseg_linknet_block_desc* d, void* stream) {
+  MISEG_CHECK_ARG(d, "linknet_block: null descriptor");
+  if (d->fmt == MISEG_FMT_F16) return miseg_f16::launch_linknet_block(d, (hipStream_t)stream);
+  return launch_linknet_block(d, (hipStream_t)stream);
 }
 
 int miseg_fpn_head_fwd(const miseg_fpn_head_desc* d, void* stream) {
@@ -504,6 +513,17 @@ int miseg_plan_add_linknet_tail(miseg_plan* p, const miseg_linknet_tail_desc* d)
   return MISEG_OK;
 }
 
+int miseg_plan_add_linknet_block(miseg_plan* p, const miseg_linknet_block_desc* d) {
+  MISEG_CHECK_ARG(p && d, "plan: null argument");
+  MISEG_CHECK_ARG(d->fmt == p->fmt, "plan: the block's storage format differs from the plan's (%d)", p->fmt);
+  MISEG_CHECK_ARG(d->in && d->wa && d->wb && d->wc && d->skip && d->out, "linknet_block: null pointer");
+  Op o{};
+  o.kind = OP_LBLOCK;
+  o.block = *d;
+  p->ops.push_back(o);
+  return MISEG_OK;
+}
+
 int miseg_plan_add_fpn_head(miseg_plan* p, const miseg_fpn_head_desc* d) {
   MISEG_CHECK_ARG(p && d, "plan: null argument");
   MISEG_CHECK_ARG(d->fmt == p->fmt, "plan: the head's storage format differs from the plan's (%d)", p->fmt);
@@ -659,6 +679,10 @@ int64_t miseg_plan_op_macs(const miseg_plan* p, int index) {
     const miseg_linknet_tail_desc& t = o.tail;
     return (int64_t)t.N * t.H * t.W * (64 * 16 + 4 * 4 * 256 + 4 * (256 + 144 * t.classes));
   }
+  if (o.kind == OP_LBLOCK) {   // per input pixel: cin*m (a) + 4 phases * 4 taps * m*m (b); per output pixel: m*64 (c)
+    const int64_t cin = o.block.cin, m = cin / 4;
+    return (int64_t)o.block.N * o.block.H * o.block.W * (cin * m + 4 * 4 * m * m + 4 * m * 64);
+  }
   if (o.kind == OP_FPNHEAD) return (int64_t)o.fhead.N * o.fhead.H * o.fhead.W * 4 * 9 * 128 * o.fhead.classes;
   if (o.kind != OP_CONV && o.kind != OP_CONV_HEAD && o.kind != OP_DENSE) return 0;
   const miseg_conv_desc& d = o.conv;
@@ -678,7 +702,7 @@ int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t bufl
   static const char* names[] = {"", "prep_input_kernel", "maxpool3x3s2_kernel", "avgpool2x2_kernel",
                                 "upsample_nearest_kernel", "upsample_bilinear2x_kernel",
                                 "scale_shift_relu_kernel", "", "", "", "", "maxpool2x2_kernel",
-                                "im2col3x3_kernel", "head_gather_kernel"};
+                                "im2col3x3_kernel", "head_gather_kernel", "linknet_block_kernel"};
   if (o.kind == OP_CONV)
     conv_kernel_name(&o.conv, buf, buflen);
   else if (o.kind == OP_CONV_HEAD)

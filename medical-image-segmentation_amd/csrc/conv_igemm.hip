@@ -862,7 +862,7 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
     return;
   }
   if (pw_thin_wanted(d, pp, kc.kind)) {
-    snprintf(buf, len, "conv_pw_thin_kernel<%d>", d->Cin / 16);
+    snprintf(buf, len, "conv_pw_thin_kernel<%d, 2>", d->Cin / 16);
     return;
   }
   static const char* shapes[] = {"2, 2, 2, 2", "4, 1, 2, 2", "4, 1, 2, 1", "2, 2, 1, 1",

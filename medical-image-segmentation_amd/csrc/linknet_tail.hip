@@ -357,4 +357,302 @@ int launch_linknet_tail(const miseg_linknet_tail_desc* d, hipStream_t stream) {
   return MISEG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// A whole LinkNet decoder block whose skip tensor has 64 channels (segmentation_models DecoderBlock
+// `decoder_stage3`: 1x1 CIN -> CIN/4, Conv2DTranspose(4, 2, 'same') CIN/4 -> CIN/4, 1x1 CIN/4 -> 64, each
+// followed by BatchNorm + ReLU, then Add with the skip tensor; /root/reference utils/model.py:188-198), for
+// CIN = 64 (the ResNets: the previous block ends on the 64-channel stage-1 skip) and CIN = 128 (the DenseNets:
+// it ends on pool2_conv's 128 channels).  Layer by layer the two CIN/4-channel tensors cost as much traffic as
+// 64-channel ones (they are stored padded for the matrix kernels): 384 B per output pixel against CIN/2 B in,
+// 128 B skip and 128 B out here.  Steps 0-2 are those of the tail kernel above without the head's halo (a
+// phase owns 4 x 32 of the block's 8 x 64 output pixels); step 3 is the 1x1 to 64 channels (four cout groups
+// of v_mfma_f32_16x16x32) with scale/shift, ReLU and the skip addition in registers: a lane holds 4
+// consecutive couts of one pixel, the four kg lanes of a pixel write 32 contiguous bytes and the four cout
+// groups complete the pixel's 128-byte line.
+// ---------------------------------------------------------------------------------------------
+struct BlockParams {
+  const h16_t* in;
+  const h16_t *wa, *wb, *wc;
+  const float *sa, *ta, *sb, *tb, *sc, *tc;
+  const h16_t* skip;
+  h16_t* out;
+  int N, H, W;            // input extent; skip and output are 2H x 2W
+  int in_pix_stride, in_row_stride;
+  long long in_img_stride;
+  int skip_pix_stride, skip_row_stride;
+  long long skip_img_stride;
+  int out_pix_stride, out_row_stride;
+  long long out_img_stride;
+  int tiles_y, tiles_x, mtiles;
+};
+
+namespace {
+constexpr int LB_OW = 2 * LT_IW, LB_OH = 2 * LT_IH;                  // 8 x 64 output pixels
+template <int CIN>
+struct LbGeom {
+  static constexpr int MID = CIN / 4;
+  static constexpr int XPITCH = CIN * 2 + 16;                       // input halo: bytes per pixel
+  static constexpr int NHI = (LT_HPX * XPITCH + 1023) / 1024;       // wave-instructions that fetch it
+  static constexpr int MPITCH = MID * 2 + 16;                       // CIN/4-channel tiles
+  static constexpr int MA = (LT_HPX * MPITCH + 1023) / 1024 * 1024;
+  static constexpr int BC = LB_OH * LB_OW * MPITCH;
+  static constexpr int LDS = MA + (BC > NHI * 1024 ? BC : NHI * 1024);
+  static constexpr int OCC = 3 * LDS <= 160 * 1024 ? 3 : 2;
+  static_assert(2 * LDS <= 160 * 1024, "two blocks per CU");
+};
+}  // namespace
+
+template <int CIN>
+__global__ __launch_bounds__(256, LbGeom<CIN>::OCC) void linknet_block_kernel(const BlockParams t) {
+  typedef LbGeom<CIN> G;
+  constexpr int MID = G::MID, MG = MID / 16, XPITCH = G::XPITCH, MPITCH = G::MPITCH;
+  constexpr int KS1 = CIN / 32;               // K steps of the first 1x1
+  constexpr int KS2 = 4 * MID / 32;           // ... of a transpose phase: k = tap * MID + channel
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = lane & 15, kg = lane >> 4;
+
+  int tile;
+  {
+    const int ntot = t.mtiles, bid = blockIdx.x;
+    const int qq = ntot >> 3, r = ntot & 7, x = bid & 7, loc = bid >> 3;
+    tile = (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + loc;
+  }
+  const int per_img = t.tiles_y * t.tiles_x;
+  const int n = tile / per_img;
+  const int trem = tile - n * per_img;
+  const int tyi = trem / t.tiles_x;
+  const int txi = trem - tyi * t.tiles_x;
+  const int y0 = tyi * LT_IH, x0 = txi * LT_IW;
+  const int Y0 = 2 * y0, X0 = 2 * x0;
+  const int Ho = 2 * t.H, Wo = 2 * t.W;
+
+  unsigned char* MA = lds;
+  unsigned char* XH = lds + G::MA;            // the output-resolution tile overlays the dead input halo
+  unsigned char* BC = lds + G::MA;
+
+  // ---- 0: input halo by LDS-DMA ----
+  {
+    const h16_t* img = t.in + n * t.in_img_stride;
+    const h16_t* zero_src = reinterpret_cast<const h16_t*>(g_zero_line);
+#pragma unroll
+    for (int j = 0; j < (G::NHI + 3) / 4; ++j) {
+      const int i = 4 * j + wave;
+      if (i < G::NHI) {
+        const int o = i * 1024 + lane * 16;
+        const int hr = o / XPITCH;
+        const int sl = (o - hr * XPITCH) >> 4;
+        const int hy = hr / LT_HW, hx = hr - hy * LT_HW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = hr < LT_HPX && sl < CIN / 8 && (unsigned)iy < (unsigned)t.H && (unsigned)ix < (unsigned)t.W;
+        const h16_t* src = ok ? img + (long long)iy * t.in_row_stride + (long long)ix * t.in_pix_stride + sl * 8 : zero_src;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(XH + i * 1024), 16, 0, 0);
+      }
+    }
+  }
+  h16x8 fa[MG][KS1], fb[MG][KS2], fc[4];
+#pragma unroll
+  for (int mg = 0; mg < MG; ++mg) {
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks)
+      fa[mg][ks] = *reinterpret_cast<const h16x8*>(t.wa + (mg * 16 + row) * CIN + ks * 32 + kg * 8);
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks)
+      fb[mg][ks] = *reinterpret_cast<const h16x8*>(t.wb + (wave * MID + mg * 16 + row) * (4 * MID) + ks * 32 + kg * 8);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) fc[g] = *reinterpret_cast<const h16x8*>(t.wc + (g * 16 + row) * 32 + kg * 8);
+  float4 sa4[MG], ta4[MG], sb4[MG], tb4[MG];
+#pragma unroll
+  for (int mg = 0; mg < MG; ++mg) {
+    sa4[mg] = *reinterpret_cast<const float4*>(t.sa + mg * 16 + 4 * kg);
+    ta4[mg] = *reinterpret_cast<const float4*>(t.ta + mg * 16 + 4 * kg);
+    sb4[mg] = *reinterpret_cast<const float4*>(t.sb + mg * 16 + 4 * kg);
+    tb4[mg] = *reinterpret_cast<const float4*>(t.tb + mg * 16 + 4 * kg);
+  }
+  float4 sc4[4], tc4[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    sc4[g] = *reinterpret_cast<const float4*>(t.sc + g * 16 + 4 * kg);
+    tc4[g] = *reinterpret_cast<const float4*>(t.tc + g * 16 + 4 * kg);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- 1: 1x1 CIN -> MID on the input tile (13 tiles of 16 pixels: wave, wave + 4, ...) ----
+  {
+    constexpr int NT1 = ((LT_HPX + 15) / 16 + 3) / 4;
+    h16x8 xb[NT1][KS1];
+#pragma unroll
+    for (int k = 0; k < NT1; ++k) {
+      const int px = (wave + 4 * k) * 16 + row;
+      const int pc = px < LT_HPX ? px : LT_HPX - 1;
+#pragma unroll
+      for (int ks = 0; ks < KS1; ++ks)
+        xb[k][ks] = *reinterpret_cast<const h16x8*>(XH + pc * XPITCH + ks * 64 + kg * 16);
+    }
+    f32x4 acc[NT1][MG];
+#pragma unroll
+    for (int k = 0; k < NT1; ++k)
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) {
+        acc[k][mg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) acc[k][mg] = mfma_16x16x32(fa[mg][ks], xb[k][ks], acc[k][mg]);
+      }
+#pragma unroll
+    for (int k = 0; k < NT1; ++k) {
+      const int px = (wave + 4 * k) * 16 + row;
+      const int pc = px < LT_HPX ? px : LT_HPX - 1;
+      const int hy = pc / LT_HW, hx = pc - hy * LT_HW;
+      const bool inside = (unsigned)(y0 - 1 + hy) < (unsigned)t.H && (unsigned)(x0 - 1 + hx) < (unsigned)t.W;
+#pragma unroll
+      for (int mg = 0; mg < MG; ++mg) {
+        uint2 o = lt_pack4(h16_relu(acc[k][mg][0] * sa4[mg].x + ta4[mg].x), h16_relu(acc[k][mg][1] * sa4[mg].y + ta4[mg].y),
+                           h16_relu(acc[k][mg][2] * sa4[mg].z + ta4[mg].z), h16_relu(acc[k][mg][3] * sa4[mg].w + ta4[mg].w));
+        if (!inside) o = make_uint2(0, 0);
+        if (px < LT_HPX) *reinterpret_cast<uint2*>(MA + px * MPITCH + mg * 32 + kg * 8) = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2: the transpose, phase (a, b) = wave: output pixels (2 r' + a, 2 c' + b), r' < 4, c' < 32 ----
+  {
+    const int pa = wave >> 1, pb = wave & 1;
+    constexpr int NT2 = LT_IH * LT_IW / 16;      // 8 tiles, four at a time
+    int koff[KS2];                               // k = ks * 32 + kg * 8 = tap * MID + channel, tap = dy * 2 + dx
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {
+      const int kidx = ks * 32 + kg * 8;
+      const int tap = kidx / MID, ch = kidx - tap * MID;
+      koff[ks] = ((tap >> 1) * LT_HW + (tap & 1)) * MPITCH + ch * 2;
+    }
+#pragma unroll
+    for (int h0 = 0; h0 < NT2; h0 += 4) {
+      h16x8 xb[4][KS2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = (h0 + k) * 16 + row;
+        const int r = (p >> 5) + pa, c = (p & 31) + pb;
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks)
+          xb[k][ks] = *reinterpret_cast<const h16x8*>(MA + (r * LT_HW + c) * MPITCH + koff[ks]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = (h0 + k) * 16 + row;
+        const int rr = p >> 5, cc = p & 31;
+#pragma unroll
+        for (int mg = 0; mg < MG; ++mg) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS2; ++ks) acc = mfma_16x16x32(fb[mg][ks], xb[k][ks], acc);
+          const uint2 o = lt_pack4(h16_relu(acc[0] * sb4[mg].x + tb4[mg].x), h16_relu(acc[1] * sb4[mg].y + tb4[mg].y),
+                                   h16_relu(acc[2] * sb4[mg].z + tb4[mg].z), h16_relu(acc[3] * sb4[mg].w + tb4[mg].w));
+          *reinterpret_cast<uint2*>(BC + ((2 * rr + pa) * LB_OW + 2 * cc + pb) * MPITCH + mg * 32 + kg * 8) = o;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3: 1x1 MID -> 64 (K padded to 32), scale/shift, ReLU, + skip: wave = 16 columns of every output row ----
+  {
+    const int ox = X0 + wave * 16 + row;
+    const h16_t* skp = t.skip + n * t.skip_img_stride + (long long)ox * t.skip_pix_stride + 4 * kg;
+    h16_t* outp = t.out + n * t.out_img_stride + (long long)ox * t.out_pix_stride + 4 * kg;
+#pragma unroll
+    for (int h0 = 0; h0 < LB_OH; h0 += 4) {
+      h16x8 xb[4];
+      uint2 sk[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oy = Y0 + h0 + i;
+        const unsigned char* px = BC + ((h0 + i) * LB_OW + wave * 16 + row) * MPITCH;
+        if constexpr (MID == 16) {
+          xb[i] = *reinterpret_cast<const h16x8*>(px + (kg & 1) * 16);
+          if (kg >= 2) xb[i] = __builtin_bit_cast(h16x8, make_uint4(0, 0, 0, 0));
+        } else {
+          xb[i] = *reinterpret_cast<const h16x8*>(px + kg * 16);
+        }
+        const bool okp = oy < Ho && ox < Wo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          sk[i][g] = okp ? *reinterpret_cast<const uint2*>(skp + (long long)oy * t.skip_row_stride + g * 16) : make_uint2(0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oy = Y0 + h0 + i;
+        const bool okp = oy < Ho && ox < Wo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          acc = mfma_16x16x32(fc[g], xb[i], acc);
+          const float v0 = h16_relu(acc[0] * sc4[g].x + tc4[g].x) + h16lo_to_f32(sk[i][g].x);
+          const float v1 = h16_relu(acc[1] * sc4[g].y + tc4[g].y) + h16hi_to_f32(sk[i][g].x);
+          const float v2 = h16_relu(acc[2] * sc4[g].z + tc4[g].z) + h16lo_to_f32(sk[i][g].y);
+          const float v3 = h16_relu(acc[3] * sc4[g].w + tc4[g].w) + h16hi_to_f32(sk[i][g].y);
+          if (okp)
+            *reinterpret_cast<uint2*>(outp + (long long)oy * t.out_row_stride + g * 16) =
+                lt_pack4(h16_act(v0, false), h16_act(v1, false), h16_act(v2, false), h16_act(v3, false));
+        }
+      }
+    }
+  }
+}
+
+int launch_linknet_block(const miseg_linknet_block_desc* d, hipStream_t stream) {
+  MISEG_CHECK_ARG(d != nullptr, "linknet_block: null descriptor");
+  MISEG_CHECK_ARG(d->in && d->wa && d->wb && d->wc && d->skip && d->out, "linknet_block: null pointer");
+  MISEG_CHECK_ARG(d->sa && d->ta && d->sb && d->tb && d->sc && d->tc, "linknet_block: null scale/shift vector");
+  MISEG_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0, "linknet_block: non-positive dimension");
+  MISEG_CHECK_ARG((d->in_pix_stride & 7) == 0 && (d->in_row_stride & 7) == 0 && (d->in_img_stride & 7) == 0 &&
+                      d->in_pix_stride >= d->cin,
+                  "linknet_block: input strides must be multiples of 8 elements, cin channels per pixel");
+  if (d->cin != 64 && d->cin != 128) {
+    set_error("linknet_block: cin=%d must be 64 or 128", d->cin);
+    return MISEG_E_UNSUPPORTED_SHAPE;
+  }
+  MISEG_CHECK_ARG((d->skip_pix_stride & 3) == 0 && (d->skip_row_stride & 3) == 0 && (d->skip_img_stride & 3) == 0 &&
+                      d->skip_pix_stride >= 64 && (d->out_pix_stride & 3) == 0 && (d->out_row_stride & 3) == 0 &&
+                      (d->out_img_stride & 3) == 0 && d->out_pix_stride >= 64,
+                  "linknet_block: skip and output strides must be multiples of 4 elements, 64 channels per pixel");
+  const uintptr_t al = (uintptr_t)d->in | (uintptr_t)d->wa | (uintptr_t)d->wb | (uintptr_t)d->wc | (uintptr_t)d->sa |
+                       (uintptr_t)d->ta | (uintptr_t)d->sb | (uintptr_t)d->tb | (uintptr_t)d->sc | (uintptr_t)d->tc;
+  MISEG_CHECK_ARG((al & 15) == 0, "linknet_block: input, weights and coefficient vectors must be 16-byte aligned");
+  MISEG_CHECK_ARG((((uintptr_t)d->skip | (uintptr_t)d->out) & 7) == 0, "linknet_block: skip / output misaligned");
+  BlockParams t;
+  t.in = (const h16_t*)d->in;
+  t.wa = (const h16_t*)d->wa; t.wb = (const h16_t*)d->wb; t.wc = (const h16_t*)d->wc;
+  t.sa = d->sa; t.ta = d->ta; t.sb = d->sb; t.tb = d->tb; t.sc = d->sc; t.tc = d->tc;
+  t.skip = (const h16_t*)d->skip;
+  t.out = (h16_t*)d->out;
+  t.N = d->N; t.H = d->H; t.W = d->W;
+  t.in_pix_stride = d->in_pix_stride; t.in_row_stride = d->in_row_stride; t.in_img_stride = d->in_img_stride;
+  t.skip_pix_stride = d->skip_pix_stride; t.skip_row_stride = d->skip_row_stride; t.skip_img_stride = d->skip_img_stride;
+  t.out_pix_stride = d->out_pix_stride; t.out_row_stride = d->out_row_stride; t.out_img_stride = d->out_img_stride;
+  t.tiles_y = (d->H + LT_IH - 1) / LT_IH;
+  t.tiles_x = (d->W + LT_IW - 1) / LT_IW;
+  const long long tiles = (long long)d->N * t.tiles_y * t.tiles_x;
+  if (tiles >= (1ll << 31)) {
+    set_error("linknet_block: too many tiles");
+    return MISEG_E_UNSUPPORTED_SHAPE;
+  }
+  t.mtiles = (int)tiles;
+  if (d->cin == 64)
+    hipLaunchKernelGGL(linknet_block_kernel<64>, dim3(t.mtiles), dim3(256), 0, stream, t);
+  else
+    hipLaunchKernelGGL(linknet_block_kernel<128>, dim3(t.mtiles), dim3(256), 0, stream, t);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("linknet_block launch failed: %s", hipGetErrorString(e));
+    return MISEG_E_HIP;
+  }
+  return MISEG_OK;
+}
+
 }  // namespace MISEG_KNS

@@ -529,6 +529,41 @@ class Engine:
         nbytes = x.n * x.h * x.w * 64 * 2 + self.n * self.h * self.wd * c * 5
         self._add(self.lib.miseg_plan_add_linknet_tail(self.plan, C.byref(d)), "decoder_stage4+final_conv", nbytes)
 
+    def _linknet_block_ok(self, i, x, skip):
+        w = self.w
+        pre = "decoder_stage%d" % i
+        m = x.c // 4
+        return (x.c in (64, 128) and skip is not None and skip.c == 64 and
+                w[pre + "a_conv"]["kernel"].shape[3] == m and
+                w[pre + "b_transpose"]["kernel"].shape[2:] == (m, m) and
+                w[pre + "c_conv"]["kernel"].shape[2:] == (m, 64))
+
+    def _linknet_block(self, i, x, skip):
+        """A decoder block with C = 64 or 128 input channels and a 64-channel skip tensor (decoder_stage3: 1x1
+        C -> C/4, transpose C/4 -> C/4, 1x1 C/4 -> 64, each BN + ReLU, + skip) as one kernel: neither C/4-channel
+        tensor reaches HBM.  Returns the block's output."""
+        pre = "decoder_stage%d" % i
+        out = self.buf(2 * x.h, 2 * x.w, 64)
+        d = L.LinknetBlockDesc()
+        d.inp = x.ptr
+        d.wa = self.conv_weight(pre + "a_conv", cin_pad=x.c)
+        d.wb = self.convT_weight(pre + "b_transpose", cin_pad=x.c // 4)
+        d.wc = self.conv_weight(pre + "c_conv", cin_pad=32)
+        d.cin = x.c
+        for key, bn in (("a", pre + "a_bn"), ("b", pre + "b_bn"), ("c", pre + "c_bn")):
+            sc, sh = self.bn_fold(bn)
+            setattr(d, "s" + key, self.dev_f32(sc))
+            setattr(d, "t" + key, self.dev_f32(sh))
+        d.skip, d.out = skip.ptr, out.ptr
+        d.N, d.H, d.W = x.n, x.h, x.w
+        d.in_pix_stride, d.in_row_stride, d.in_img_stride = x.pix, x.row, x.img
+        d.skip_pix_stride, d.skip_row_stride, d.skip_img_stride = skip.pix, skip.row, skip.img
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = out.pix, out.row, out.img
+        d.fmt = self.fmt
+        nbytes = x.n * x.h * x.w * x.c * 2 + 2 * x.n * out.h * out.w * 64 * 2
+        self._add(self.lib.miseg_plan_add_linknet_block(self.plan, C.byref(d)), pre, nbytes)
+        return out
+
     def _fpn_head_gather(self, x):
         """final_upsampling (bilinear x2) + head_conv + activation + collapse with the channel contraction at
         HALF resolution: both layers are linear, so the nine taps' contractions W[tap][:, c] . x run as one 1x1
@@ -707,6 +742,10 @@ class Engine:
                     self._linknet_tail(x)
                     x = None
                     break
+                if self.fuse_tail and i < len(skips) and self._linknet_block_ok(i, x, skips[i]):
+                    x = self._linknet_block(i, x, skips[i])
+                    self.taps["decoder_stage%d_out" % i] = x
+                    continue
                 # the transpose convolution's input channels (C / 4) padded to a multiple of 64 with zero
                 # channels and zero weights: the ring kernel takes such a layer, the generic one is 1.5-2x slower
                 ca = self.w["decoder_stage%da_conv" % i]["kernel"].shape[3]

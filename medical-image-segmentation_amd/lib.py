@@ -62,6 +62,20 @@ class LinknetTailDesc(C.Structure):
     ]
 
 
+class LinknetBlockDesc(C.Structure):
+    """Mirror of `miseg_linknet_block_desc`."""
+    _fields_ = [
+        ("inp", C.c_void_p), ("wa", C.c_void_p), ("wb", C.c_void_p), ("wc", C.c_void_p),
+        ("sa", C.c_void_p), ("ta", C.c_void_p), ("sb", C.c_void_p), ("tb", C.c_void_p),
+        ("sc", C.c_void_p), ("tc", C.c_void_p), ("skip", C.c_void_p), ("out", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("in_pix_stride", C.c_int32), ("in_row_stride", C.c_int32), ("in_img_stride", C.c_int64),
+        ("skip_pix_stride", C.c_int32), ("skip_row_stride", C.c_int32), ("skip_img_stride", C.c_int64),
+        ("out_pix_stride", C.c_int32), ("out_row_stride", C.c_int32), ("out_img_stride", C.c_int64),
+        ("fmt", C.c_int32), ("cin", C.c_int32),
+    ]
+
+
 class FpnHeadDesc(C.Structure):
     """Mirror of `miseg_fpn_head_desc`."""
     _fields_ = [
@@ -100,6 +114,7 @@ SIGNATURES = {
     "miseg_conv_c32_head_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _VP]),
     "miseg_dense_layer_fwd": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), _VP]),
     "miseg_linknet_tail_fwd": (C.c_int, [C.POINTER(LinknetTailDesc), _VP]),
+    "miseg_linknet_block_fwd": (C.c_int, [C.POINTER(LinknetBlockDesc), _VP]),
     "miseg_fpn_head_fwd": (C.c_int, [C.POINTER(FpnHeadDesc), _VP]),
     "miseg_prep_input": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
     "miseg_prep_input_indicator": (C.c_int, [_FP, _VP, _FP, _FP, _I32, _I32, _I32, _VP]),
@@ -164,6 +179,7 @@ SIGNATURES = {
     "miseg_plan_add_conv_c32_head": (C.c_int, [_VP, C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "miseg_plan_add_dense_layer": (C.c_int, [_VP, C.POINTER(ConvDesc), C.POINTER(ConvDesc)]),
     "miseg_plan_add_linknet_tail": (C.c_int, [_VP, C.POINTER(LinknetTailDesc)]),
+    "miseg_plan_add_linknet_block": (C.c_int, [_VP, C.POINTER(LinknetBlockDesc)]),
     "miseg_plan_add_fpn_head": (C.c_int, [_VP, C.POINTER(FpnHeadDesc)]),
     "miseg_plan_add_prep_input": (C.c_int, [_VP, _FP, _VP, _FP, _FP, _I32, _I32, _I32]),
     "miseg_plan_add_maxpool3x3s2": (C.c_int, [_VP, _VP, _VP, _FP, _FP, _I32, _I32, _I32, _I32, _I32, _I32]),

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Copy what scripts/profile_round.sh left under gpurun_out/r02c into profiles/ under this round's names:
+"""Copy what scripts/profile_round.sh left under gpurun_out/r02d into profiles/ under this round's names:
 the bench lines, the per-kernel duration summaries as rocprofv3 wrote them, the two counter passes of every
 configuration trimmed to this library's kernels and the columns that matter, and their reduction to HBM bytes
 per launch (scripts/pmc_traffic.py).
 
-usage: scripts/collect_profiles.py [gpurun_out/r02c] [r02_c]"""
+usage: scripts/collect_profiles.py [gpurun_out/r02d] [r02_d]"""
 import csv
 import os
 import shutil
@@ -12,8 +12,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02c")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02_c"
+src = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02d")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02_d"
 dst = os.path.join(ROOT, "profiles")
 COLS = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name",
         "Counter_Value"]

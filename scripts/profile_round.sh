@@ -1,9 +1,9 @@
-# One GPU call that produces everything profiles/r02_c_* is reduced from: the default bench line, per-kernel
+# One GPU call that produces everything profiles/r02_d_* is reduced from: the default bench line, per-kernel
 # durations (one and two plans in flight, training step), and the two HBM counter passes (FETCH_SIZE, WRITE_SIZE: each
 # needs a run of its own) of the headline, DenseNet-169 and training configurations.
 set -e
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/r02c
+O=$GRAFT_REPO_ROOT/gpurun_out/r02d
 mkdir -p $O
 timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err
 tail -c 400 $O/bench.json; echo

@@ -223,3 +223,34 @@ def check_engine(enc, dec, hw, n, classes, **engine_options):
         assert abs(losses.f1_score(gt, got) - losses.f1_score(gt, want)) < 1e-3
         assert abs(losses.iou_score(gt, got) - losses.iou_score(gt, want)) < 1e-3
         assert abs(losses.cce_dice_loss(gt, got) - losses.cce_dice_loss(gt, want)) < 2e-3
+
+
+@pytest.mark.parametrize("enc,hw,n", [("resnet18", (96, 160), 2), ("densenet121", (64, 224), 1), ("resnet34", (160, 96), 1)])
+@pytest.mark.parametrize("storage", ["fp16", "bf16"])
+def test_linknet_fused_block_matches_layerwise(enc, hw, n, storage):
+    """decoder_stage3 of a LinkNet (1x1 64 -> 16, transpose 16 -> 16, 1x1 16 -> 64, + skip; segmentation_models
+    DecoderBlock, /root/reference utils/model.py:188-198) as one kernel against the same block run layer by layer:
+    same operands, same rounding points, so the 64-channel outputs differ by rounding flips only.  Ragged
+    8 x 64 output patches and several images are among the cases."""
+    import miseg_amd
+    from miseg_amd import engine, netspec
+    from oracle import nets
+    h, w = hw
+    weights = nets.init_weights(nets.build_spec(enc, "Linknet", 3), seed=11, randomize_bn=True)
+    g = netspec.build_graph(enc, "Linknet", (h, w, 3), 3)
+    x = torch.from_numpy(make_inputs(n, h, w, seed=5)).cuda()
+    outs = []
+    for fuse in (True, False):
+        eng = engine.Engine(g, weights, batch=n, storage=storage, fuse_tail=fuse)
+        eng.forward(x)
+        kernels = [eng.op_kernel(i) for i in range(eng.num_ops)]
+        assert ("linknet_block_kernel" in kernels) == fuse
+        outs.append(eng.taps["decoder_stage3_out"].torch().float().cpu().numpy())
+        del eng
+    a, b = outs
+    assert a.shape == b.shape == (n, h // 2, w // 2, 64)
+    scale = np.abs(b).max()
+    ulp = 2.0 ** (-10 if storage == "fp16" else -7)
+    # a rounding flip of a 16-channel intermediate moves an output by a few of its own roundings
+    assert np.abs(a - b).max() <= 8 * ulp * scale, (np.abs(a - b).max(), scale)
+    assert np.mean(np.abs(a - b) > ulp * np.maximum(np.abs(b), 1e-3 * scale)) < 0.02

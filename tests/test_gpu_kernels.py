@@ -291,7 +291,7 @@ def test_conv_pointwise_short_contraction(env, shape, mode):
     d.out_dtype = L.DT_BF16
     buf = C.create_string_buffer(128)
     L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
-    assert buf.value.decode().startswith("conv_pw_thin_kernel<%d>" % (cin // 16)), buf.value
+    assert buf.value.decode().startswith("conv_pw_thin_kernel<%d, 2>" % (cin // 16)), buf.value
 
 
 def test_conv_epilogues(env):
