@@ -242,7 +242,7 @@ int miseg_linknet_tail_fwd(const miseg_linknet_tail_desc* d, void* stream);
  *   wa  : [m][cin]; wb: [4][m][2][2][m] (phase, cout, dy, dx, cin) as in miseg_linknet_tail_desc;
  *   wc  : [64][32] (cout, cin; cin >= m zero)
  *   sa, ta, sb, tb: m floats each; sc, tc: 64 floats
- *   skip, out: 16-bit [N][2H][2W][>= 64 channels] (strides in elements, multiples of 4)
+ *   skip, out: 16-bit [N][2H][2W][>= 64 channels] (strides in elements, multiples of 8; 16-byte aligned)
  */
 typedef struct miseg_linknet_block_desc {
   const void* in;

@@ -366,9 +366,9 @@ int launch_linknet_tail(const miseg_linknet_tail_desc* d, hipStream_t stream) {
 // 64-channel ones (they are stored padded for the matrix kernels): 384 B per output pixel against CIN/2 B in,
 // 128 B skip and 128 B out here.  Steps 0-2 are those of the tail kernel above without the head's halo (a
 // phase owns 4 x 32 of the block's 8 x 64 output pixels); step 3 is the 1x1 to 64 channels (four cout groups
-// of v_mfma_f32_16x16x32) with scale/shift, ReLU and the skip addition in registers: a lane holds 4
-// consecutive couts of one pixel, the four kg lanes of a pixel write 32 contiguous bytes and the four cout
-// groups complete the pixel's 128-byte line.
+// of v_mfma_f32_16x16x32, their weight rows dealt so that a lane holds 8 consecutive couts of one pixel over a
+// pair of them) with scale/shift, ReLU and the skip addition in registers: 16-byte skip loads and stores, the
+// four kg lanes of a pixel cover 64 contiguous bytes and the two pairs complete the pixel's 128-byte line.
 // ---------------------------------------------------------------------------------------------
 struct BlockParams {
   const h16_t* in;
@@ -463,8 +463,12 @@ __global__ __launch_bounds__(256, LbGeom<CIN>::OCC) void linknet_block_kernel(co
     for (int ks = 0; ks < KS2; ++ks)
       fb[mg][ks] = *reinterpret_cast<const h16x8*>(t.wb + (wave * MID + mg * 16 + row) * (4 * MID) + ks * 32 + kg * 8);
   }
+  // the last 1x1's weight rows are dealt so that a lane ends up with 8 CONSECUTIVE couts over a pair of matrix
+  // instructions: instruction (pair, half) row 4 q + j holds cout 32 pair + 8 q + 4 half + j, hence lane
+  // (pixel, kg) accumulator j of it is cout 32 pair + 8 kg + 4 half + j: 16-byte skip loads and stores
 #pragma unroll
-  for (int g = 0; g < 4; ++g) fc[g] = *reinterpret_cast<const h16x8*>(t.wc + (g * 16 + row) * 32 + kg * 8);
+  for (int g = 0; g < 4; ++g)
+    fc[g] = *reinterpret_cast<const h16x8*>(t.wc + ((g >> 1) * 32 + 8 * (row >> 2) + 4 * (g & 1) + (row & 3)) * 32 + kg * 8);
   float4 sa4[MG], ta4[MG], sb4[MG], tb4[MG];
 #pragma unroll
   for (int mg = 0; mg < MG; ++mg) {
@@ -476,8 +480,8 @@ __global__ __launch_bounds__(256, LbGeom<CIN>::OCC) void linknet_block_kernel(co
   float4 sc4[4], tc4[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    sc4[g] = *reinterpret_cast<const float4*>(t.sc + g * 16 + 4 * kg);
-    tc4[g] = *reinterpret_cast<const float4*>(t.tc + g * 16 + 4 * kg);
+    sc4[g] = *reinterpret_cast<const float4*>(t.sc + (g >> 1) * 32 + 8 * kg + 4 * (g & 1));
+    tc4[g] = *reinterpret_cast<const float4*>(t.tc + (g >> 1) * 32 + 8 * kg + 4 * (g & 1));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -563,12 +567,12 @@ __global__ __launch_bounds__(256, LbGeom<CIN>::OCC) void linknet_block_kernel(co
   // ---- 3: 1x1 MID -> 64 (K padded to 32), scale/shift, ReLU, + skip: wave = 16 columns of every output row ----
   {
     const int ox = X0 + wave * 16 + row;
-    const h16_t* skp = t.skip + n * t.skip_img_stride + (long long)ox * t.skip_pix_stride + 4 * kg;
-    h16_t* outp = t.out + n * t.out_img_stride + (long long)ox * t.out_pix_stride + 4 * kg;
+    const h16_t* skp = t.skip + n * t.skip_img_stride + (long long)ox * t.skip_pix_stride + 8 * kg;
+    h16_t* outp = t.out + n * t.out_img_stride + (long long)ox * t.out_pix_stride + 8 * kg;
 #pragma unroll
     for (int h0 = 0; h0 < LB_OH; h0 += 4) {
       h16x8 xb[4];
-      uint2 sk[4][4];
+      uint4 sk[4][2];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int oy = Y0 + h0 + i;
@@ -581,24 +585,33 @@ __global__ __launch_bounds__(256, LbGeom<CIN>::OCC) void linknet_block_kernel(co
         }
         const bool okp = oy < Ho && ox < Wo;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          sk[i][g] = okp ? *reinterpret_cast<const uint2*>(skp + (long long)oy * t.skip_row_stride + g * 16) : make_uint2(0, 0);
+        for (int pr = 0; pr < 2; ++pr)
+          sk[i][pr] = okp ? *reinterpret_cast<const uint4*>(skp + (long long)oy * t.skip_row_stride + pr * 32) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int oy = Y0 + h0 + i;
         const bool okp = oy < Ho && ox < Wo;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          acc = mfma_16x16x32(fc[g], xb[i], acc);
-          const float v0 = h16_relu(acc[0] * sc4[g].x + tc4[g].x) + h16lo_to_f32(sk[i][g].x);
-          const float v1 = h16_relu(acc[1] * sc4[g].y + tc4[g].y) + h16hi_to_f32(sk[i][g].x);
-          const float v2 = h16_relu(acc[2] * sc4[g].z + tc4[g].z) + h16lo_to_f32(sk[i][g].y);
-          const float v3 = h16_relu(acc[3] * sc4[g].w + tc4[g].w) + h16hi_to_f32(sk[i][g].y);
-          if (okp)
-            *reinterpret_cast<uint2*>(outp + (long long)oy * t.out_row_stride + g * 16) =
-                lt_pack4(h16_act(v0, false), h16_act(v1, false), h16_act(v2, false), h16_act(v3, false));
+        for (int pr = 0; pr < 2; ++pr) {
+          f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+          lo = mfma_16x16x32(fc[2 * pr], xb[i], lo);
+          hi = mfma_16x16x32(fc[2 * pr + 1], xb[i], hi);
+          const float4 s0 = sc4[2 * pr], t0 = tc4[2 * pr], s1 = sc4[2 * pr + 1], t1 = tc4[2 * pr + 1];
+          const uint4 r = sk[i][pr];
+          const float v0 = h16_relu(lo[0] * s0.x + t0.x) + h16lo_to_f32(r.x);
+          const float v1 = h16_relu(lo[1] * s0.y + t0.y) + h16hi_to_f32(r.x);
+          const float v2 = h16_relu(lo[2] * s0.z + t0.z) + h16lo_to_f32(r.y);
+          const float v3 = h16_relu(lo[3] * s0.w + t0.w) + h16hi_to_f32(r.y);
+          const float v4 = h16_relu(hi[0] * s1.x + t1.x) + h16lo_to_f32(r.z);
+          const float v5 = h16_relu(hi[1] * s1.y + t1.y) + h16hi_to_f32(r.z);
+          const float v6 = h16_relu(hi[2] * s1.z + t1.z) + h16lo_to_f32(r.w);
+          const float v7 = h16_relu(hi[3] * s1.w + t1.w) + h16hi_to_f32(r.w);
+          if (okp) {
+            const uint2 a = lt_pack4(h16_act(v0, false), h16_act(v1, false), h16_act(v2, false), h16_act(v3, false));
+            const uint2 b = lt_pack4(h16_act(v4, false), h16_act(v5, false), h16_act(v6, false), h16_act(v7, false));
+            *reinterpret_cast<uint4*>(outp + (long long)oy * t.out_row_stride + pr * 32) = make_uint4(a.x, a.y, b.x, b.y);
+          }
         }
       }
     }
@@ -617,14 +630,14 @@ int launch_linknet_block(const miseg_linknet_block_desc* d, hipStream_t stream) 
     set_error("linknet_block: cin=%d must be 64 or 128", d->cin);
     return MISEG_E_UNSUPPORTED_SHAPE;
   }
-  MISEG_CHECK_ARG((d->skip_pix_stride & 3) == 0 && (d->skip_row_stride & 3) == 0 && (d->skip_img_stride & 3) == 0 &&
-                      d->skip_pix_stride >= 64 && (d->out_pix_stride & 3) == 0 && (d->out_row_stride & 3) == 0 &&
-                      (d->out_img_stride & 3) == 0 && d->out_pix_stride >= 64,
-                  "linknet_block: skip and output strides must be multiples of 4 elements, 64 channels per pixel");
+  MISEG_CHECK_ARG((d->skip_pix_stride & 7) == 0 && (d->skip_row_stride & 7) == 0 && (d->skip_img_stride & 7) == 0 &&
+                      d->skip_pix_stride >= 64 && (d->out_pix_stride & 7) == 0 && (d->out_row_stride & 7) == 0 &&
+                      (d->out_img_stride & 7) == 0 && d->out_pix_stride >= 64,
+                  "linknet_block: skip and output strides must be multiples of 8 elements, 64 channels per pixel");
   const uintptr_t al = (uintptr_t)d->in | (uintptr_t)d->wa | (uintptr_t)d->wb | (uintptr_t)d->wc | (uintptr_t)d->sa |
                        (uintptr_t)d->ta | (uintptr_t)d->sb | (uintptr_t)d->tb | (uintptr_t)d->sc | (uintptr_t)d->tc;
   MISEG_CHECK_ARG((al & 15) == 0, "linknet_block: input, weights and coefficient vectors must be 16-byte aligned");
-  MISEG_CHECK_ARG((((uintptr_t)d->skip | (uintptr_t)d->out) & 7) == 0, "linknet_block: skip / output misaligned");
+  MISEG_CHECK_ARG((((uintptr_t)d->skip | (uintptr_t)d->out) & 15) == 0, "linknet_block: skip / output misaligned");
   BlockParams t;
   t.in = (const h16_t*)d->in;
   t.wa = (const h16_t*)d->wa; t.wb = (const h16_t*)d->wb; t.wc = (const h16_t*)d->wc;
