@@ -926,9 +926,10 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.res_shift = d->res_upsample_shift;
   p.out2_linear = d->out2_linear ? 1 : 0;
   p.in_valid_c = d->in_valid_c > 0 ? d->in_valid_c : d->Cin;
-  // one million output pixels: from there on the epilogue's HBM traffic, not its latency, is what a generic
-  // launch waits for (measured on the full-resolution 1x1 layers of LinkNet and FPN: 1.1-2.2x faster)
-  p.direct = (long long)d->N * d->Ho * d->Wo >= (1 << 20);
+  // one million output pixels, or 64 million output values: from there on the epilogue's HBM traffic, not its
+  // latency, is what a generic launch waits for (measured on the full-resolution 1x1 layers of LinkNet and FPN:
+  // 1.1-2.2x faster; LinkNet's 416 -> 640 layer at 120x160x8)
+  p.direct = (long long)d->N * d->Ho * d->Wo >= (1 << 20) || (long long)d->N * d->Ho * d->Wo * d->Cout >= (64ll << 20);
   auto al = [](const void* ptr, long long a, long long b, long long c, int mask) {
     return (((uintptr_t)ptr & 15) == 0) && ((a | b | c) & mask) == 0;
   };
