@@ -300,8 +300,8 @@ def extra_config(encoder, decoder, classes, h, w, batch, streams, dev, storage, 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="images per plan (one launch sequence)")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent plans per GPU, each on its own HIP stream; a step runs every plan once "
@@ -317,8 +317,8 @@ def main():
                     help="skip the DenseNet-169 LinkNet / FPN inference lines (the `configs` array)")
     ap.add_argument("--train-encoder", default="resnet18")
     ap.add_argument("--train-batch", type=int, default=16, help="training images per GPU per step")
-    ap.add_argument("--train-steps", type=int, default=5)
-    ap.add_argument("--train-warmup", type=int, default=1)
+    ap.add_argument("--train-steps", type=int, default=10)
+    ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--per-op", action="store_true", help="print a per-kernel table to stderr")
     ap.add_argument("--storage", default="fp16", choices=["fp16", "bf16"],
                     help="16-bit storage format of activations and weights (same kernels, rate and bytes; fp16 is "
