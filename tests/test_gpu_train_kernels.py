@@ -226,16 +226,20 @@ def test_bn_stats_and_backward(env):
     np.testing.assert_allclose(dx.float().cpu().numpy(), want_dx, rtol=2e-2, atol=2e-3)
 
 
-def test_input_stats(env):
+@pytest.mark.parametrize("shape", [(2, 16, 20), (1, 15, 21), (3, 97, 131), (1, 1, 3)])
+def test_input_stats(env, shape):
+    """bn_data's batch statistics of the fp32 input: groups of four pixels by 16-byte loads, the last
+    pixels % 4 one by one."""
     L, lib, dev = env
     rng = np.random.default_rng(2)
-    x = rng.uniform(0, 1, (2, 16, 20, 3)).astype(np.float32)
+    n, h, w = shape
+    x = rng.uniform(0, 1, (n, h, w, 3)).astype(np.float32)
     beta = rng.normal(0, 0.1, 3).astype(np.float32)
     xd, b_ = df32(x, dev), df32(beta, dev)
     mm, mv = torch.zeros(3, device=dev), torch.ones(3, device=dev)
     mean, var, scale, shift = (torch.zeros(3, device=dev) for _ in range(4))
     ws = torch.zeros(6, dtype=torch.float64, device=dev)
-    L.check(lib.miseg_input_stats_fwd(xd.data_ptr(), 2 * 16 * 20, b_.data_ptr(), mm.data_ptr(), mv.data_ptr(),
+    L.check(lib.miseg_input_stats_fwd(xd.data_ptr(), n * h * w, b_.data_ptr(), mm.data_ptr(), mv.data_ptr(),
                                       0.99, 2e-5, mean.data_ptr(), var.data_ptr(), scale.data_ptr(),
                                       shift.data_ptr(), ws.data_ptr(), None))
     x2 = x.reshape(-1, 3).astype(np.float64)
