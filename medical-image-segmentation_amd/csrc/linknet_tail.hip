@@ -7,15 +7,16 @@
 // they cost 4 x 64 B per output pixel of HBM traffic against 32 B in (per output pixel) and 15 B
 // out for the fused form, and the whole tail is 2 kMAC per pixel.
 //
-// A block of 4 waves owns 8 x 64 output pixels = 4 x 32 input pixels (three blocks per CU):
+// A block of 4 waves owns 8 x 64 output pixels = 4 x 32 input pixels (four blocks per CU):
 //   0. the (4+2) x (32+2) input pixels x 64 channels arrive by LDS-DMA (144-byte pixel pitch);
 //   1. 1x1 64 -> 16 on those 204 pixels (v_mfma_f32_16x16x32: 16 couts x 16 pixels x 32 k),
 //      scale/shift + ReLU, zero outside the image (the transpose's padding) -> LDS;
 //   2. the transpose as four 2x2 phase convolutions, one phase per wave (its [16][64] weights in
 //      registers; K = 4 taps x 16 channels), on the (8+2) x (64+2) output pixels the head's 3x3
-//      needs -> LDS, over the dead input tile;
-//   3. 1x1 16 -> 16 in place (K = 16: the upper half of the 32-deep instruction is zero),
-//      zero outside the image (the head's padding);
+//      needs;
+//   3. 1x1 16 -> 16 on the transpose's accumulators where they lie: a lane's 4 channels of its pixel
+//      are 4 of its 8 k slots of the 32-deep instruction (the others zero, the weights dealt to
+//      match), zero outside the image (the head's padding) -> LDS, over the dead input tile;
 //   4. head: 9 taps x 16 channels = five 32-deep steps per 16 pixels, bias, activation, collapse;
 //      rows leave as contiguous 16-byte stores through a wave-private LDS staging area.
 // After step 0 no LDS-DMA is pending, so all LDS traffic is ordinary compiler-scheduled code.
@@ -44,7 +45,9 @@ constexpr int LT_HPX = LT_HH * LT_HW;              // 204 input pixels with halo
 constexpr int LT_XPITCH = 144;
 constexpr int LT_NHI = (LT_HPX * LT_XPITCH + 1023) / 1024;   // 29 wave-instructions
 constexpr int LT_MPITCH = 48;                      // 16 channels + 16 bytes of padding
-constexpr int LT_MA = (LT_HPX * LT_MPITCH + 1023) / 1024 * 1024;   // 1x1 output tile
+constexpr int LT_APITCH = 32;                      // the first 1x1's tile: 16 channels, no padding (its 16-pixel
+                                                   // fragments and quad writes cover contiguous bytes)
+constexpr int LT_MA = (LT_HPX * LT_APITCH + 1023) / 1024 * 1024;   // 1x1 output tile
 constexpr int LT_OW = 2 * LT_IW + 2, LT_OH = 2 * LT_IH + 2;
 constexpr int LT_OPX = LT_OH * LT_OW;              // 660 output pixels with halo
 constexpr int LT_PW = LT_IW + 1, LT_PH = LT_IH + 1;          // pixels of one phase: 5 x 33
@@ -52,10 +55,11 @@ constexpr int LT_PPX = LT_PH * LT_PW;
 constexpr int LT_BC_OFF = LT_MA;                   // input tile first, then the output-resolution tile
 constexpr int LT_BC = LT_OPX * LT_MPITCH;
 static_assert(LT_NHI * 1024 <= LT_BC + 1024, "the input tile fits under the output-resolution tile");
-constexpr int LT_SCR_OFF = LT_BC_OFF + (LT_BC > LT_NHI * 1024 ? LT_BC : LT_NHI * 1024);
+constexpr int LT_SCR_OFF = 0;                      // the head's staging area overlays the first 1x1's dead tile
 constexpr int LT_SCR_WAVE = 1024 + 256;
-constexpr int LT_LDS = LT_SCR_OFF + 4 * LT_SCR_WAVE;
-static_assert(3 * LT_LDS <= 160 * 1024, "three blocks per CU");
+static_assert(4 * LT_SCR_WAVE <= LT_MA, "the staging area fits under the first tile");
+constexpr int LT_LDS = LT_BC_OFF + (LT_BC > LT_NHI * 1024 ? LT_BC : LT_NHI * 1024);
+static_assert(4 * LT_LDS <= 160 * 1024, "four blocks per CU");
 typedef f32x4_t f32x4;
 
 __device__ __forceinline__ uint2 lt_pack4(float a, float b, float c, float d) {
@@ -63,7 +67,7 @@ __device__ __forceinline__ uint2 lt_pack4(float a, float b, float c, float d) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(256, 3) void linknet_tail_kernel(const TailParams t, const ConvParams hd) {
+__global__ __launch_bounds__(256, 4) void linknet_tail_kernel(const TailParams t, const ConvParams hd) {
   __shared__ __attribute__((aligned(1024))) unsigned char lds[LT_LDS];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -116,7 +120,12 @@ __global__ __launch_bounds__(256, 3) void linknet_tail_kernel(const TailParams t
     fa[ks] = *reinterpret_cast<const h16x8*>(t.wa + row * 64 + ks * 32 + kg * 8);
     fb[ks] = *reinterpret_cast<const h16x8*>(t.wb + (wave * 16 + row) * 64 + ks * 32 + kg * 8);
   }
-  fc = *reinterpret_cast<const h16x8*>(t.wc + row * 32 + kg * 8);
+  // the second 1x1 consumes the transpose's accumulators as they lie: lane (pixel, kg) holds channels 4 kg .. 4 kg + 3
+  // of its pixel, which become k slots 8 kg .. 8 kg + 3 of the 32-deep instruction (slots 8 kg + 4 .. 8 kg + 7 zero)
+  {
+    const uint2 w4 = *reinterpret_cast<const uint2*>(t.wc + row * 32 + 4 * kg);
+    fc = __builtin_bit_cast(h16x8, make_uint4(w4.x, w4.y, 0u, 0u));
+  }
 #pragma unroll
   for (int s = 0; s < 5; ++s) fd[s] = *reinterpret_cast<const h16x8*>(t.wd + row * 160 + s * 32 + kg * 8);
   const float4 sa4 = *reinterpret_cast<const float4*>(t.sa + 4 * kg), ta4 = *reinterpret_cast<const float4*>(t.ta + 4 * kg);
@@ -158,12 +167,13 @@ __global__ __launch_bounds__(256, 3) void linknet_tail_kernel(const TailParams t
       uint2 o = lt_pack4(h16_relu(acc[k][0] * sa4.x + ta4.x), h16_relu(acc[k][1] * sa4.y + ta4.y),
                          h16_relu(acc[k][2] * sa4.z + ta4.z), h16_relu(acc[k][3] * sa4.w + ta4.w));
       if (!inside) o = make_uint2(0, 0);
-      if (px < LT_HPX) *reinterpret_cast<uint2*>(MA + px * LT_MPITCH + kg * 8) = o;
+      if (px < LT_HPX) *reinterpret_cast<uint2*>(MA + px * LT_APITCH + kg * 8) = o;
     }
   }
   __syncthreads();
 
-  // ---- 2: the transpose, phase (a, b) = wave: 11 tiles in two batches ----
+  // ---- 2 + 3: the transpose, phase (a, b) = wave (11 tiles in two batches), and the 1x1 16 -> 16 behind it on
+  // the tile's accumulators in registers; zero outside the image (the head's padding) ----
   {
     const int pa = wave >> 1, pb = wave & 1;
     constexpr int NT2 = (LT_PPX + 15) / 16, HB = (NT2 + 1) / 2;
@@ -177,7 +187,7 @@ __global__ __launch_bounds__(256, 3) void linknet_tail_kernel(const TailParams t
         const int r = pc / LT_PW, c = pc - r * LT_PW;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)      // taps (dy, dx) = (ks, kg >> 1), channels 8 (kg & 1) ..
-          xb[k][ks] = *reinterpret_cast<const h16x8*>(MA + ((r + ks) * LT_HW + c + (kg >> 1)) * LT_MPITCH + (kg & 1) * 16);
+          xb[k][ks] = *reinterpret_cast<const h16x8*>(MA + ((r + ks) * LT_HW + c + (kg >> 1)) * LT_APITCH + (kg & 1) * 16);
       }
 #pragma unroll
       for (int k = 0; k < HB; ++k) {
@@ -188,40 +198,17 @@ __global__ __launch_bounds__(256, 3) void linknet_tail_kernel(const TailParams t
         const int p = (h0 + k) * 16 + row;
         const int pc = p < LT_PPX ? p : LT_PPX - 1;
         const int r = pc / LT_PW, c = pc - r * LT_PW;
-        const uint2 o = lt_pack4(h16_relu(acc[0] * sb4.x + tb4.x), h16_relu(acc[1] * sb4.y + tb4.y),
-                                 h16_relu(acc[2] * sb4.z + tb4.z), h16_relu(acc[3] * sb4.w + tb4.w));
-        if (p < LT_PPX)
-          *reinterpret_cast<uint2*>(BC + ((2 * r - pa + 1) * LT_OW + (2 * c - pb + 1)) * LT_MPITCH + kg * 8) = o;
+        const uint2 ob = lt_pack4(h16_relu(acc[0] * sb4.x + tb4.x), h16_relu(acc[1] * sb4.y + tb4.y),
+                                  h16_relu(acc[2] * sb4.z + tb4.z), h16_relu(acc[3] * sb4.w + tb4.w));
+        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+        acc2 = mfma_16x16x32(fc, __builtin_bit_cast(h16x8, make_uint4(ob.x, ob.y, 0u, 0u)), acc2);
+        const int ry = 2 * r - pa + 1, rx = 2 * c - pb + 1;
+        const bool inside = (unsigned)(Y0 - 1 + ry) < (unsigned)Ho && (unsigned)(X0 - 1 + rx) < (unsigned)Wo;
+        uint2 o = lt_pack4(h16_relu(acc2[0] * sc4.x + tc4.x), h16_relu(acc2[1] * sc4.y + tc4.y),
+                           h16_relu(acc2[2] * sc4.z + tc4.z), h16_relu(acc2[3] * sc4.w + tc4.w));
+        if (!inside) o = make_uint2(0, 0);
+        if (p < LT_PPX) *reinterpret_cast<uint2*>(BC + (ry * LT_OW + rx) * LT_MPITCH + kg * 8) = o;
       }
-    }
-  }
-  __syncthreads();
-
-  // ---- 3: 1x1 16 -> 16 in place (42 tiles: wave, wave + 4, ...) ----
-  {
-    constexpr int NT3 = ((LT_OPX + 15) / 16 + 3) / 4;
-    h16x8 xb[NT3];
-#pragma unroll
-    for (int k = 0; k < NT3; ++k) {
-      const int p = (wave + 4 * k) * 16 + row;
-      const int pc = p < LT_OPX ? p : LT_OPX - 1;
-      xb[k] = *reinterpret_cast<const h16x8*>(BC + pc * LT_MPITCH + (kg & 1) * 16);
-      if (kg >= 2) xb[k] = __builtin_bit_cast(h16x8, make_uint4(0, 0, 0, 0));
-    }
-    // (a tile past the end re-reads the last pixel, which another wave may already have rewritten:
-    // its result is not stored)
-#pragma unroll
-    for (int k = 0; k < NT3; ++k) {
-      const int p = (wave + 4 * k) * 16 + row;
-      const int pc = p < LT_OPX ? p : LT_OPX - 1;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = mfma_16x16x32(fc, xb[k], acc);
-      const int ry = pc / LT_OW, rx = pc - ry * LT_OW;
-      const bool inside = (unsigned)(Y0 - 1 + ry) < (unsigned)Ho && (unsigned)(X0 - 1 + rx) < (unsigned)Wo;
-      uint2 o = lt_pack4(h16_relu(acc[0] * sc4.x + tc4.x), h16_relu(acc[1] * sc4.y + tc4.y),
-                         h16_relu(acc[2] * sc4.z + tc4.z), h16_relu(acc[3] * sc4.w + tc4.w));
-      if (!inside) o = make_uint2(0, 0);
-      if (p < LT_OPX) *reinterpret_cast<uint2*>(BC + p * LT_MPITCH + kg * 8) = o;
     }
   }
   __syncthreads();
