@@ -495,6 +495,10 @@ def main():
                 extra_config("densenet169", "Linknet", args.classes, h, w, 8, 2, dev, args.storage),
                 extra_config("densenet169", "FPN", args.classes, h, w, 4, 2, dev, args.storage),
             ]
+            if args.storage == "fp16":
+                # the headline configuration once more on bf16 storage (same kernels and bytes; fp32 residual stream)
+                result["configs"].append(extra_config(args.encoder, args.decoder, args.classes, h, w, args.batch,
+                                                      args.streams, dev, "bf16"))
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.encoder, args.decoder, args.classes, h, w, weights)
         print(json.dumps(result), flush=True)
