@@ -24,6 +24,12 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak of MI355X
 HBM_PEAK_GBS = 8000.0
+# forward GFLOP per 1920x2560 image of the layer graphs as the reference builds them (2 x MAC over every
+# convolution and transpose convolution; linear in H x W).  The engine runs some layers in an algebraically
+# equal form with fewer multiply-adds (FPN's final_stage and finest pyramid level), so the executed
+# figure can be lower than the graph's.
+GRAPH_GFLOP_1920x2560 = {("resnet34", "U-Net"): 1770.6, ("resnet18", "U-Net"): 1408.2,
+                         ("densenet169", "Linknet"): 781.9, ("densenet169", "FPN"): 3666.2}
 
 
 def synthetic_images(n, h, w, seed=1234):
@@ -104,12 +110,20 @@ def pmc_traffic(kernel, batch, h, w, encoder, decoder):
     return sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in fam) / sum(v["dispatches"] for v in fam)
 
 
-def training_leg(args, dev, rank, world, dist, h, w, augment=False):
+def training_leg(args, dev, rank, world, dist, h, w, augment=False, global_batch=0):
     """Second headline configuration: ResNet-18 U-Net training steps (forward on batch statistics,
     cce+Dice loss, backward, bucketed gradient all-reduce over RCCL overlapped with the backward
     pass, Adam) on a fixed synthetic batch per GPU -- the loop behind `model.fit`,
-    /root/reference model_train.py:284-329 with --loss dice (:172-173)."""
+    /root/reference model_train.py:284-329 with --loss dice (:172-173).
+    global_batch = 0: `--train-batch` images per GPU per step (weak scaling).  global_batch = G: the G images of
+    a step are split evenly over the ranks, G / world each (strong scaling: BASELINE config 3's "batch 16,
+    data-parallel 1/2/4/8 GPUs", the split tf.distribute makes of the global batch)."""
     from miseg_amd import netspec, trainer
+    args = argparse.Namespace(**vars(args))
+    if global_batch:
+        if global_batch % world:
+            raise SystemExit("--train-global-batch %d does not divide over %d ranks" % (global_batch, world))
+        args.train_batch = global_batch // world
     graph = netspec.build_graph(args.train_encoder, args.decoder, (h, w, 3), args.classes)
     tr = trainer.Trainer(graph, build_weights(graph), args.train_batch, device=str(dev), loss="cce_dice",
                          world_size=world)
@@ -160,11 +174,14 @@ def training_leg(args, dev, rank, world, dist, h, w, augment=False):
                                                                  args.decoder),
             "value": args.train_batch * world * args.train_steps / elapsed, "unit": "images/s",
             "ms_per_step": 1e3 * elapsed / args.train_steps, "steps": args.train_steps,
-            "warmup": args.train_warmup, "scaling": "weak",
+            "warmup": args.train_warmup, "scaling": "strong" if global_batch else "weak",
+            "global_batch": args.train_batch * world, "n_gpus": world,
             "dtype": "bf16 activations/gradients, fp32 accumulation and master weights",
             "config": {"workload": "%s %s training %dx%dx3, %d classes, cce+Dice loss, Adam, batch %d "
-                                   "per GPU per step%s" % (args.train_encoder, args.decoder, h, w,
+                                   "per GPU per step%s%s" % (args.train_encoder, args.decoder, h, w,
                                                            args.classes, args.train_batch,
+                                                           " (global batch %d split over %d GPUs)" % (global_batch, world)
+                                                           if global_batch else "",
                                                            ", on-device augmentation (flips, brightness, contrast, "
                                                            "hue, saturation) inside the step" if augment else ""),
                        "parallelism": "data parallel, bucketed RCCL all-reduce overlapped with backward"
@@ -217,7 +234,23 @@ def train_roofline(prof, ms_per_step, traffic_key=None):
     return head
 
 
-def extra_config(encoder, decoder, classes, h, w, batch, streams, dev, storage, steps=6, warmup=2):
+def whole_pass(encoder, decoder, h, w, ips, gflop_exec, gbytes_img, nops):
+    """The whole forward pass against both peaks.  `mfma_frac` prices the multiply-adds the kernels execute;
+    `mfma_frac_graph` prices the layer graph as the reference states it (the figure a layer-by-layer run would
+    execute), for the networks whose graph figure is tabulated."""
+    out = {"gflop_per_image_executed": gflop_exec, "algorithmic_gbytes_per_image": gbytes_img,
+           "mfma_frac": ips * gflop_exec / 1e3 / MFMA_BF16_PEAK_TFLOPS,
+           "mfma_frac_uses": "gflop_per_image_executed",
+           "hbm_frac": ips * gbytes_img / HBM_PEAK_GBS, "launches_per_pass": int(nops)}
+    g = GRAPH_GFLOP_1920x2560.get((encoder, decoder))
+    if g is not None:
+        g = g * (h * w) / (1920.0 * 2560.0)
+        out["gflop_per_image_graph"] = g
+        out["mfma_frac_graph"] = ips * g / 1e3 / MFMA_BF16_PEAK_TFLOPS
+    return out
+
+
+def extra_config(encoder, decoder, classes, h, w, batch, streams, dev, storage, steps=20, warmup=3, repeats=3):
     """One more inference configuration of BASELINE.json (the DenseNet-169 models), measured the
     same way as the headline one on this rank's GPU: images/s over `steps` steps of `streams`
     concurrent plans of `batch` images, the dominant kernel's roofline from per-launch HIP events,
@@ -239,11 +272,14 @@ def extra_config(encoder, decoder, classes, h, w, batch, streams, dev, storage, 
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    rates = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        rates.append(batch * streams * steps / (time.perf_counter() - t0))
+    elapsed = batch * streams * steps / float(np.median(rates))
     eng = engs[0]
     nops = eng.num_ops
     op_ms = np.zeros(nops)
@@ -270,6 +306,8 @@ def extra_config(encoder, decoder, classes, h, w, batch, streams, dev, storage, 
     out = {
         "metric": "images/sec at %dx%dx3 %s %s inference" % (h, w, enc_names.get(encoder, encoder), decoder),
         "value": ips, "unit": "images/s", "steps": steps, "warmup": warmup,
+        "repeats": {"count": repeats, "min": min(rates), "median": float(np.median(rates)), "max": max(rates),
+                    "note": "`value` is the median of the repeats of `steps` steps each"},
         "ms_per_step": 1e3 * elapsed / steps, "dtype": storage,
         "config": {"workload": "%s %s inference %dx%dx3, %d classes, random-init weights, %d concurrent plan(s) of %d "
                                "images, %s storage" % (encoder, decoder, h, w, classes, streams, batch, storage)},
@@ -286,10 +324,7 @@ def extra_config(encoder, decoder, classes, h, w, batch, streams, dev, storage, 
                                   "frac": 2.0 * macs.sum() / (op_ms[conv].sum() * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                   "ms_per_pass": float(op_ms[conv].sum()),
                                   "non_conv_ms_per_pass": float(op_ms[~conv].sum())},
-            "whole_pass": {"gflop_per_image": gflop_img, "algorithmic_gbytes_per_image": gbytes_img,
-                           "mfma_frac": ips * gflop_img / 1e3 / MFMA_BF16_PEAK_TFLOPS,
-                           "hbm_frac": ips * gbytes_img / HBM_PEAK_GBS,
-                           "launches_per_pass": int(nops)},
+            "whole_pass": whole_pass(encoder, decoder, h, w, ips, gflop_img, gbytes_img, nops),
         },
     }
     del engs, eng
@@ -317,6 +352,10 @@ def main():
                     help="skip the DenseNet-169 LinkNet / FPN inference lines (the `configs` array)")
     ap.add_argument("--train-encoder", default="resnet18")
     ap.add_argument("--train-batch", type=int, default=16, help="training images per GPU per step")
+    ap.add_argument("--train-global-batch", type=int, default=16,
+                    help="with more than one GPU, a second training leg (`train_strong`) splits this many images "
+                         "per step evenly over the GPUs (strong scaling: BASELINE config 3); 0 skips it.  On one "
+                         "GPU it coincides with --train-batch 16 and is not run twice")
     ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--per-op", action="store_true", help="print a per-kernel table to stderr")
@@ -392,8 +431,17 @@ def main():
 
     train = None
     train5 = None
+    train_strong = None
+    ranks_seen = None
+    if dist is not None:
+        # what RCCL itself saw: the sum of one 1 per rank
+        t = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
     if not args.no_train:
         train = training_leg(args, dev, rank, world, dist, h, w)
+        if world > 1 and args.train_global_batch and args.train_global_batch != args.train_batch * world:
+            train_strong = training_leg(args, dev, rank, world, dist, h, w, global_batch=args.train_global_batch)
         if not args.no_extra and (args.encoder, args.decoder) == ("resnet34", "U-Net"):
             # BASELINE.json config 5: DenseNet-169 FPN training (Dice loss, data parallel), 4 images per GPU
             a5 = argparse.Namespace(**vars(args))
@@ -473,7 +521,7 @@ def main():
                 "frac": dom_tflops / MFMA_BF16_PEAK_TFLOPS,
                 "traffic": pmc_traffic(dom_name, args.batch, h, w, args.encoder, args.decoder),
                 "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes), "
-                                "from the committed PMC passes profiles/r02_d_pmc_*.csv",
+                                "from the committed PMC passes named in PMC_FILES",
                 "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
                 "all_conv_launches": {
                     "achieved": conv_flops / (conv_ms * 1e-3) / 1e12,
@@ -482,8 +530,16 @@ def main():
                     "non_conv_ms_per_step": float(op_ms[~is_conv].sum())},
             },
         }
+        if dist is not None:
+            result["world"] = {"world_size": dist.get_world_size(), "ranks_in_rccl_allreduce": ranks_seen,
+                               "backend": dist.get_backend()}
+        result["roofline"]["whole_pass"] = whole_pass(args.encoder, args.decoder, h, w, images / elapsed / world,
+                                                      conv_flops / args.batch / 1e9, sum(eng.op_bytes) / args.batch / 1e9,
+                                                      nops)
         if train is not None:
             result["train"] = train
+        if train_strong is not None:
+            result["train_strong"] = train_strong
         if train5 is not None:
             result["train_configs"] = [train5]
         if not args.no_extra and (args.encoder, args.decoder) == ("resnet34", "U-Net"):

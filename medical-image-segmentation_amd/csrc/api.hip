@@ -225,6 +225,7 @@ int miseg_linknet_tail_fwd(const miseg_linknet_tail_desc* d, void* stream) {
 
 int miseg_linknet_block_fwd(const miseg_linknet_block_desc* d, void* stream) {
   MISEG_CHECK_ARG(d, "linknet_block: null descriptor");
+  MISEG_CHECK_FMT(d->fmt);
   if (d->fmt == MISEG_FMT_F16) return miseg_f16::launch_linknet_block(d, (hipStream_t)stream);
   return launch_linknet_block(d, (hipStream_t)stream);
 }
@@ -465,7 +466,7 @@ int miseg_plan_add_conv(miseg_plan* p, const miseg_conv_desc* d) {
   MISEG_CHECK_ARG(p && d, "plan: null argument");
   MISEG_CHECK_ARG(d->fmt == p->fmt, "plan: the convolution's storage format (%d) differs from the plan's (%d)",
                   (int)d->fmt, p->fmt);
-  int rc = validate_conv(d);
+  int rc = p->fmt == MISEG_FMT_F16 ? miseg_f16::validate_conv(d) : validate_conv(d);
   if (rc != MISEG_OK) return rc;
   Op o{};
   o.kind = OP_CONV;
@@ -478,7 +479,8 @@ int miseg_plan_add_conv_c32_head(miseg_plan* p, const miseg_conv_desc* body, con
   MISEG_CHECK_ARG(p && body && head, "plan: null argument");
   MISEG_CHECK_ARG(body->fmt == p->fmt && head->fmt == p->fmt,
                   "plan: the convolutions' storage format differs from the plan's (%d)", p->fmt);
-  int rc = validate_conv_c32_head(body, head);
+  int rc = p->fmt == MISEG_FMT_F16 ? miseg_f16::validate_conv_c32_head(body, head)
+                                   : validate_conv_c32_head(body, head);
   if (rc != MISEG_OK) return rc;
   Op o{};
   o.kind = OP_CONV_HEAD;
@@ -492,7 +494,8 @@ int miseg_plan_add_dense_layer(miseg_plan* p, const miseg_conv_desc* c1, const m
   MISEG_CHECK_ARG(p && c1 && c2, "plan: null argument");
   MISEG_CHECK_ARG(c1->fmt == p->fmt && c2->fmt == p->fmt,
                   "plan: the convolutions' storage format differs from the plan's (%d)", p->fmt);
-  int rc = validate_dense_layer(c1, c2);
+  // the kernel's coefficient area holds twice as many input channels with fp16 storage
+  int rc = p->fmt == MISEG_FMT_F16 ? miseg_f16::validate_dense_layer(c1, c2) : validate_dense_layer(c1, c2);
   if (rc != MISEG_OK) return rc;
   Op o{};
   o.kind = OP_DENSE;
@@ -505,7 +508,8 @@ int miseg_plan_add_dense_layer(miseg_plan* p, const miseg_conv_desc* c1, const m
 int miseg_plan_add_linknet_tail(miseg_plan* p, const miseg_linknet_tail_desc* d) {
   MISEG_CHECK_ARG(p && d, "plan: null argument");
   MISEG_CHECK_ARG(d->fmt == p->fmt, "plan: the tail's storage format differs from the plan's (%d)", p->fmt);
-  MISEG_CHECK_ARG(d->in && d->wa && d->wb && d->wc && d->wd && d->out, "linknet_tail: null pointer");
+  const int rc = p->fmt == MISEG_FMT_F16 ? miseg_f16::validate_linknet_tail(d) : validate_linknet_tail(d);
+  if (rc != MISEG_OK) return rc;
   Op o{};
   o.kind = OP_LTAIL;
   o.tail = *d;
@@ -516,7 +520,8 @@ int miseg_plan_add_linknet_tail(miseg_plan* p, const miseg_linknet_tail_desc* d)
 int miseg_plan_add_linknet_block(miseg_plan* p, const miseg_linknet_block_desc* d) {
   MISEG_CHECK_ARG(p && d, "plan: null argument");
   MISEG_CHECK_ARG(d->fmt == p->fmt, "plan: the block's storage format differs from the plan's (%d)", p->fmt);
-  MISEG_CHECK_ARG(d->in && d->wa && d->wb && d->wc && d->skip && d->out, "linknet_block: null pointer");
+  const int rc = p->fmt == MISEG_FMT_F16 ? miseg_f16::validate_linknet_block(d) : validate_linknet_block(d);
+  if (rc != MISEG_OK) return rc;
   Op o{};
   o.kind = OP_LBLOCK;
   o.block = *d;
@@ -527,7 +532,8 @@ int miseg_plan_add_linknet_block(miseg_plan* p, const miseg_linknet_block_desc* 
 int miseg_plan_add_fpn_head(miseg_plan* p, const miseg_fpn_head_desc* d) {
   MISEG_CHECK_ARG(p && d, "plan: null argument");
   MISEG_CHECK_ARG(d->fmt == p->fmt, "plan: the head's storage format differs from the plan's (%d)", p->fmt);
-  MISEG_CHECK_ARG(d->in && d->wd && d->out, "fpn_head: null pointer");
+  const int rc = p->fmt == MISEG_FMT_F16 ? miseg_f16::validate_fpn_head(d) : validate_fpn_head(d);
+  if (rc != MISEG_OK) return rc;
   Op o{};
   o.kind = OP_FPNHEAD;
   o.fhead = *d;

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256, 3) void fpn_head_kernel(const FpnHeadParams t,
   }
 }
 
-int launch_fpn_head(const miseg_fpn_head_desc* d, hipStream_t stream) {
+// Everything the kernel and its grid assume about a descriptor; called when a plan records the op and again at launch.
+int validate_fpn_head(const miseg_fpn_head_desc* d) {
   MISEG_CHECK_ARG(d != nullptr, "fpn_head: null descriptor");
   MISEG_CHECK_ARG(d->in && d->wd && d->out, "fpn_head: null pointer");
   MISEG_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0, "fpn_head: non-positive dimension");
@@ -264,6 +265,16 @@ int launch_fpn_head(const miseg_fpn_head_desc* d, hipStream_t stream) {
                       d->in_pix_stride >= 128 && (((uintptr_t)d->in | (uintptr_t)d->wd) & 15) == 0,
                   "fpn_head: input needs 128 channels per pixel, strides in multiples of 8 elements, 16-byte alignment");
   MISEG_CHECK_ARG(((uintptr_t)d->out & 3) == 0, "fpn_head: output misaligned");
+  // the output is (N, 2H, 2W, classes) fp32: a pixel must hold the classes, rows and images must not overlap
+  MISEG_CHECK_ARG(d->out_pix_stride >= d->classes && d->out_row_stride >= 2ll * d->W * d->out_pix_stride &&
+                      d->out_img_stride >= 2ll * d->H * d->out_row_stride,
+                  "fpn_head: output strides do not hold a (2H, 2W, classes) image");
+  return MISEG_OK;
+}
+
+int launch_fpn_head(const miseg_fpn_head_desc* d, hipStream_t stream) {
+  const int rc = validate_fpn_head(d);
+  if (rc != MISEG_OK) return rc;
   FpnHeadParams t;
   t.in = (const h16_t*)d->in;
   t.wd = (const h16_t*)d->wd;

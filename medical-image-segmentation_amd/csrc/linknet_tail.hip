@@ -294,7 +294,8 @@ __global__ __launch_bounds__(256, 4) void linknet_tail_kernel(const TailParams t
   }
 }
 
-int launch_linknet_tail(const miseg_linknet_tail_desc* d, hipStream_t stream) {
+// Everything the kernel and its grid assume about a descriptor; called when a plan records the op and again at launch.
+int validate_linknet_tail(const miseg_linknet_tail_desc* d) {
   MISEG_CHECK_ARG(d != nullptr, "linknet_tail: null descriptor");
   MISEG_CHECK_ARG(d->in && d->wa && d->wb && d->wc && d->wd && d->out, "linknet_tail: null pointer");
   MISEG_CHECK_ARG(d->sa && d->ta && d->sb && d->tb && d->sc && d->tc, "linknet_tail: null scale/shift vector");
@@ -313,6 +314,16 @@ int launch_linknet_tail(const miseg_linknet_tail_desc* d, hipStream_t stream) {
                        (uintptr_t)d->tc;
   MISEG_CHECK_ARG((al & 15) == 0, "linknet_tail: input, weights and coefficient vectors must be 16-byte aligned");
   MISEG_CHECK_ARG(((uintptr_t)d->out & 3) == 0, "linknet_tail: output misaligned");
+  // the output is (N, 2H, 2W, classes) fp32: a pixel must hold the classes, rows and images must not overlap
+  MISEG_CHECK_ARG(d->out_pix_stride >= d->classes && d->out_row_stride >= 2ll * d->W * d->out_pix_stride &&
+                      d->out_img_stride >= 2ll * d->H * d->out_row_stride,
+                  "linknet_tail: output strides do not hold a (2H, 2W, classes) image");
+  return MISEG_OK;
+}
+
+int launch_linknet_tail(const miseg_linknet_tail_desc* d, hipStream_t stream) {
+  const int rc = validate_linknet_tail(d);
+  if (rc != MISEG_OK) return rc;
   TailParams t;
   t.in = (const h16_t*)d->in;
   t.wa = (const h16_t*)d->wa; t.wb = (const h16_t*)d->wb; t.wc = (const h16_t*)d->wc; t.wd = (const h16_t*)d->wd;
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(256, LbGeom<CIN>::OCC) void linknet_block_kernel(co
   }
 }
 
-int launch_linknet_block(const miseg_linknet_block_desc* d, hipStream_t stream) {
+int validate_linknet_block(const miseg_linknet_block_desc* d) {
   MISEG_CHECK_ARG(d != nullptr, "linknet_block: null descriptor");
   MISEG_CHECK_ARG(d->in && d->wa && d->wb && d->wc && d->skip && d->out, "linknet_block: null pointer");
   MISEG_CHECK_ARG(d->sa && d->ta && d->sb && d->tb && d->sc && d->tc, "linknet_block: null scale/shift vector");
@@ -625,6 +636,17 @@ int launch_linknet_block(const miseg_linknet_block_desc* d, hipStream_t stream) 
                        (uintptr_t)d->ta | (uintptr_t)d->sb | (uintptr_t)d->tb | (uintptr_t)d->sc | (uintptr_t)d->tc;
   MISEG_CHECK_ARG((al & 15) == 0, "linknet_block: input, weights and coefficient vectors must be 16-byte aligned");
   MISEG_CHECK_ARG((((uintptr_t)d->skip | (uintptr_t)d->out) & 15) == 0, "linknet_block: skip / output misaligned");
+  // skip and output are (N, 2H, 2W, 64): rows and images must not overlap
+  MISEG_CHECK_ARG(d->out_row_stride >= 2ll * d->W * d->out_pix_stride && d->out_img_stride >= 2ll * d->H * d->out_row_stride &&
+                      d->skip_row_stride >= 2ll * d->W * d->skip_pix_stride &&
+                      d->skip_img_stride >= 2ll * d->H * d->skip_row_stride,
+                  "linknet_block: skip / output strides do not hold a (2H, 2W, 64) image");
+  return MISEG_OK;
+}
+
+int launch_linknet_block(const miseg_linknet_block_desc* d, hipStream_t stream) {
+  const int rc = validate_linknet_block(d);
+  if (rc != MISEG_OK) return rc;
   BlockParams t;
   t.in = (const h16_t*)d->in;
   t.wa = (const h16_t*)d->wa; t.wb = (const h16_t*)d->wb; t.wc = (const h16_t*)d->wc;

@@ -393,23 +393,31 @@ class Engine:
         self._maxpool(relu, cat.slice(0, c), name="pool1")
         for bi, nl in enumerate(block_layers):
             blk = "conv%d" % (bi + 2)
-            mid = self.buf(h, w, 128) if not self.fuse_dense else \
-                View(torch.empty((0, 128), dtype=self.tdtype, device=self.device), self.n, h, w, 128)
+            mid = self.buf(h, w, 128) if not self.fuse_dense else None
+            nomid = View(torch.empty((0, 128), dtype=self.tdtype, device=self.device), self.n, h, w, 128)
             for li in range(nl):
                 n = "%s_block%d" % (blk, li + 1)
                 s0, t0 = self.bn_fold(n + "_0_bn")
                 s1, t1 = self.bn_fold(n + "_1_bn")
+                fused = False
                 if self.fuse_dense:
                     d1, n1 = self.conv(n + "_1_conv", cat.slice(0, c), self.conv_weight(n + "_1_conv"), 128, 1,
                                        scale=s1, shift=t1, act=L.ACT_RELU, in_scale=s0, in_shift=t0,
                                        build_only=True)
-                    d2, n2 = self.conv(n + "_2_conv", mid, self.conv_weight(n + "_2_conv"), 32, 3, pad=1,
+                    d2, n2 = self.conv(n + "_2_conv", nomid, self.conv_weight(n + "_2_conv"), 32, 3, pad=1,
                                        out=cat.slice(c, 32), build_only=True)
                     d2.inp = None
                     n2 -= self.n * h * w * 128 * 2       # the 3x3's input never reaches HBM
-                    self._add(self.lib.miseg_plan_add_dense_layer(self.plan, C.byref(d1), C.byref(d2)),
-                              n + "_1_conv+_2_conv", n1 + n2)
-                else:
+                    rc = self.lib.miseg_plan_add_dense_layer(self.plan, C.byref(d1), C.byref(d2))
+                    # the one-kernel layer keeps the input BatchNorm's coefficients in LDS and takes as many
+                    # input channels as fit there (DenseNet-201's last conv5 layers exceed it on bf16
+                    # storage): such a layer runs as its two convolutions
+                    fused = rc != L.E_UNSUPPORTED_SHAPE
+                    if fused:
+                        self._add(rc, n + "_1_conv+_2_conv", n1 + n2)
+                if not fused:
+                    if mid is None:
+                        mid = self.buf(h, w, 128)
                     self.conv(n + "_1_conv", cat.slice(0, c), self.conv_weight(n + "_1_conv"), 128, 1,
                               out=mid, scale=s1, shift=t1, act=L.ACT_RELU, in_scale=s0, in_shift=t0)
                     self.conv(n + "_2_conv", mid, self.conv_weight(n + "_2_conv"), 32, 3, pad=1,
@@ -706,7 +714,7 @@ class Engine:
                 h, w = 2 * h, 2 * w
                 sc = skip_syms[i].c if i < len(skip_syms) else 0
                 # more than 32 channels: padded (zero channels, zero weights) to a multiple of 64, which is
-                # what the LDS-DMA kernels take (VGG's last stage concatenates 32 + 64)
+                # what the LDS-DMA kernels take
                 cb = self.buf(h, w, _ceil32(f + sc) if f + sc <= 32 else (f + sc + 63) // 64 * 64)
                 concat.append(cb)
                 if sc:

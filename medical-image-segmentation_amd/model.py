@@ -88,7 +88,11 @@ class LayerView:
 
 
 class Model:
-    def __init__(self, graph, weights=None, seed=None, device="cuda:0"):
+    def __init__(self, graph, weights=None, seed=None, device=None):
+        if device is None:
+            # the process's current GPU: under one process per GPU (model_train.py / predict.py with
+            # several --gpu entries) every rank has selected its own card before it builds a model
+            device = "cuda:%d" % torch.cuda.current_device() if torch.cuda.is_available() else "cuda:0"
         self.graph = graph
         self.weights = weights if weights is not None else W.init_weights(graph, seed=seed)
         self._name = graph.name
@@ -188,22 +192,30 @@ class Model:
             self._engines[batch] = e
         return e
 
+    RANGE_CHECK_EVERY = 32
+
     def _forward(self, batch):
         """Inference forward pass on the engine.  The engine stores activations in fp16, whose range ends at
         65504 (the kernels' conversions saturate there): activations of trained networks stay within a few
-        tens, a deep network with untrained weights may not.  The first batch a plan runs is therefore
-        followed by a look at the largest magnitude any of its 16-bit buffers holds; a plan that reached the
-        end of the range is replaced, from then on, by one with bf16 storage (fp32's range, 8 significand
-        bits), and the batch is run again."""
+        tens, a deep network with untrained weights may not.  The first batch a plan runs, and every
+        RANGE_CHECK_EVERY-th after it (one pass over the plan's buffers costs about a fifth of a forward pass,
+        so it is not made per batch), is therefore followed by a look at the largest magnitude any of its
+        16-bit buffers holds; a plan that reached the end of the range is replaced, from then on, by one with
+        bf16 storage (fp32's range, 8 significand bits), and the batch is run again.  New weights
+        (`set_weights`, training) start the check over.  What the look cannot see are the tensors the fused
+        kernels keep on chip (a DenseNet layer's 128 channels, the C/4-channel tensors of LinkNet's blocks, the
+        U-Net tail's 32 channels): they saturate the same way, and their consumers' outputs are inspected."""
         eng = self._engine(batch.shape[0])
         probs = eng.forward(batch)
-        if eng.storage == "fp16" and not getattr(eng, "range_checked", False):
-            peak = 0.0
+        count = getattr(eng, "range_batches", 0)
+        eng.range_batches = count + 1
+        if eng.storage == "fp16" and count % self.RANGE_CHECK_EVERY == 0:
+            peak = torch.zeros((), dtype=torch.float32, device=probs.device)
             for t in eng._keep:
                 if t.dtype == torch.float16 and t.numel():
                     lo, hi = torch.aminmax(t)
-                    peak = max(peak, abs(float(lo)), abs(float(hi)))
-            eng.range_checked = True
+                    peak = torch.maximum(peak, torch.maximum(lo.abs(), hi.abs()).float())
+            peak = float(peak)                  # one device -> host read for the whole plan
             if not peak < 65000.0:          # saturated, or NaN
                 import warnings
                 warnings.warn("activations of %s reach the end of the fp16 range: its inference plans use bf16 "

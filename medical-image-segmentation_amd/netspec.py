@@ -336,7 +336,9 @@ def build_graph(encoder, decoder, input_shape, classes, activation=None, tempera
     else:
         raise ValueError("unsupported encoder %r (supported: %s)" %
                          (encoder, sorted(list(RESNET_UNITS) + list(DENSENET_LAYERS) + list(VGG_BLOCKS))))
-    skips = [g.sym(k) for k in BACKBONE_FEATURES[encoder]]
+    # segmentation_models' Unet, Linknet and FPN all ask Backbones.get_feature_layers(name, n=4): of the VGGs'
+    # five listed layers the four deepest are skips and the last decoder stage has none
+    skips = [g.sym(k) for k in BACKBONE_FEATURES[encoder][:4]]
     g.skip_layers = [s.layer for s in skips]
     g.encoder_output = x.layer
     g.encoder_layers = list(g.layers)

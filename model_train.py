@@ -74,7 +74,8 @@ def train(encoder, decoder, dataset, loss, learning_rate, learning_rate_factor, 
     distributed = "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1
     rank = int(os.environ.get("RANK", "0"))
     if distributed:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        # a GPU listed twice (--gpu 0,0) carries two ranks
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         dist.init_process_group("nccl")
     chief = rank == 0
     if seed:
@@ -138,9 +139,10 @@ def train(encoder, decoder, dataset, loss, learning_rate, learning_rate_factor, 
         if resume:
             model = load_model(model_path=str(Path(resume)), input_shape=input_shape, loss_function=loss_function,
                                optimizer=Adam(learning_rate=learning_rate))
-            # the checkpoint does not carry per-layer trainable flags: a run that was started with a
-            # frozen encoder stays frozen after --resume
-            model.encoder_freeze = bool(encoder_freeze)
+            # the checkpoint carries per-layer trainable flags and load_model restores them (as Keras'
+            # load_model does for the reference, model_train.py:276-281): a run that was started with a
+            # frozen encoder stays frozen after --resume; --encoder_freeze can only add the freeze
+            model.encoder_freeze = bool(getattr(model, "encoder_freeze", False)) or bool(encoder_freeze)
         else:
             model = make_model(encoder, decoder, input_shape, classes, learning_rate, loss_function, metrics,
                                encoder_freeze, model_name, seed=seed)
@@ -228,7 +230,7 @@ def main():
     gpus = [g for g in str(a.gpu).split(",") if g != ""]
     if len(gpus) > 1 and "RANK" not in os.environ:
         # one process per GPU; the children see the same arguments and find RANK in their environment
-        env = dict(os.environ, HIP_VISIBLE_DEVICES=",".join(gpus))
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=",".join(dict.fromkeys(g.strip() for g in gpus)))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(len(gpus)),
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"),
                os.path.abspath(__file__)] + sys.argv[1:]

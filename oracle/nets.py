@@ -119,8 +119,9 @@ def _vgg_spec(s, blocks):
         for i in range(reps):
             s.conv("block%d_conv%d" % (b + 1, i + 1), 3, cin, f, bias=True, init="glorot_uniform")
             cin = f
-    # sm Backbones feature layers: the last convolution of every block, deep -> shallow
-    return list(VGG_FILTERS[::-1]), cin
+    # sm Backbones feature layers: the last convolution of every block, deep -> shallow; the
+    # decoders take get_feature_layers(name, n=4), i.e. the four deepest
+    return list(VGG_FILTERS[::-1])[:4], cin
 
 
 def _conv_bn(s, name, k, cin, cout):
@@ -328,7 +329,7 @@ def _vgg_forward(c, x, blocks):
             x = c.tap(name, ops.relu(c.conv(x, name, pad=1)))
         feats.append(x)
         x = ops.maxpool2x2(x)
-    return x, feats[::-1]
+    return x, feats[::-1][:4]            # get_feature_layers(name, n=4): block1_conv2 is not a skip
 
 
 def _center(c, x):

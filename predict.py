@@ -6,6 +6,8 @@
 """
 import argparse
 import os
+import subprocess
+import sys
 from pathlib import Path
 
 
@@ -31,13 +33,24 @@ def main():
     p.add_argument("--use-bias", default=False, action="store_true")
     p.add_argument("--reclassify", default=False, action="store_true")
     p.add_argument("--remove-artifacts", default=False, action="store_true")
-    p.add_argument("--gpu", default=0)
+    p.add_argument("--gpu", default=0, help="GPU index, or several separated by commas: the sorted image list "
+                                             "is then dealt over one process per GPU, nothing is exchanged.")
     a = p.parse_args()
     if a.use_bias_layer and a.use_bias:
         raise ValueError("Cannot use both bias layer and bias.")
     if str(a.gpu).strip() == "-1":
         raise SystemExit("--gpu -1 (CPU) is not available: this implementation runs on MI355X GPUs only")
-    os.environ.setdefault("HIP_VISIBLE_DEVICES", str(a.gpu))
+    gpus = [g for g in str(a.gpu).split(",") if g.strip() != ""]
+    if len(gpus) > 1 and "RANK" not in os.environ:
+        # one process per GPU, started before anything here touches a GPU; the children see the same
+        # arguments and find RANK / WORLD_SIZE / LOCAL_RANK in their environment
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=",".join(dict.fromkeys(g.strip() for g in gpus)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(len(gpus)),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29532"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+    if len(gpus) == 1 and "RANK" not in os.environ:
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", gpus[0].strip())
     from utils.data import SUPPORTED_IMAGE_TYPES
     from utils.predict import predict
 

@@ -49,6 +49,39 @@ def test_two_rank_sharding(tmp_path, n_items):
     assert abs(len(r["gathered"][0]) - len(r["gathered"][1])) <= 1
 
 
+def _predict_files_worker(rank, world, images, out_dir):
+    """What a rank of `predict.py --gpu 0,1` does before it touches a GPU: reads RANK / WORLD_SIZE
+    and picks its files of the sorted list."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+    from utils.predict import files_of_rank
+    files, r, w = files_of_rank(images)
+    assert (r, w) == (rank, world)
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("\n".join("%s_prediction.png" % os.path.splitext(os.path.basename(x))[0] for x in files))
+
+
+@pytest.mark.parametrize("n_files,world", [(5, 2), (4, 2), (1, 2), (7, 3)])
+def test_prediction_files_are_dealt_over_ranks_exactly_once(tmp_path, n_files, world):
+    """Multi-GPU inference shards the sorted file list of /root/reference utils/predict.py:125-131,152
+    over one process per GPU with no collective: the union of the names the ranks would write is
+    every file exactly once."""
+    from PIL import Image
+    import numpy as np
+    images = os.path.join(str(tmp_path), "images")
+    os.makedirs(images)
+    for i in range(n_files):
+        Image.fromarray(np.zeros((8, 8, 3), np.uint8)).save(os.path.join(images, "slide%02d.png" % i))
+    mp.spawn(_predict_files_worker, args=(world, images, str(tmp_path)), nprocs=world, join=True)
+    names = []
+    for r in range(world):
+        with open(os.path.join(str(tmp_path), "rank%d.txt" % r)) as f:
+            names += [n for n in f.read().split("\n") if n]
+    assert sorted(names) == ["slide%02d_prediction.png" % i for i in range(n_files)]
+    assert len(set(names)) == n_files
+
+
 def test_tile_ranges_match_reference_patch_predict():
     import miseg_amd
     from miseg_amd import shard

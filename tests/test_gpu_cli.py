@@ -78,6 +78,15 @@ def test_train_predict_evaluate_cli(pkg, tmp_path):
     assert preds == ["s00_prediction.png", "s01_prediction.png"]
     p = np.asarray(Image.open(os.path.join(work, "pred", preds[0])))
     assert p.shape == (64, 96) and p.max() <= 2
+    # two processes on the one GPU of the test box (the --gpu 0,1 path: predict.py re-launches itself under
+    # torch.distributed.run, every rank segments its share of the sorted files, nothing is exchanged):
+    # every file is written exactly once and the masks are those of the one-process run
+    _run([os.path.join(ROOT, "predict.py"), "--model", model_path, "--images", os.path.join(data, "test", "images"),
+          "--output", os.path.join(work, "pred2"), "--grayscale", "--gpu", "0,0"], cwd=work)
+    assert sorted(os.listdir(os.path.join(work, "pred2"))) == preds
+    for name in preds:
+        assert np.array_equal(np.asarray(Image.open(os.path.join(work, "pred2", name))),
+                              np.asarray(Image.open(os.path.join(work, "pred", name))))
     _run([os.path.join(ROOT, "predict.py"), "--model", model_path, "--images", big, "--output",
           os.path.join(work, "pred_big")], cwd=work)
     q = np.asarray(Image.open(os.path.join(work, "pred_big", "slide_prediction.png")))

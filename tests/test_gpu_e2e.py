@@ -37,7 +37,7 @@ CONFIGS = [
     ("resnet34", "FPN", (64, 96), 2, 4),       # four classes
     ("resnet50", "U-Net", (64, 96), 1, 3),     # bottleneck units (classification_models residual_bottleneck_block)
     ("resnet50", "Linknet", (64, 64), 2, 3),
-    ("vgg16", "U-Net", (64, 96), 1, 3),        # biased convolutions with ReLU, 2x2 max pools, five skips, centre blocks
+    ("vgg16", "U-Net", (64, 96), 1, 3),        # biased convolutions with ReLU, 2x2 max pools, four skips, centre blocks
     ("vgg16", "Linknet", (64, 64), 2, 3),
     ("vgg19", "FPN", (64, 64), 1, 1),
 ]
@@ -256,16 +256,35 @@ def test_linknet_fused_block_matches_layerwise(enc, hw, n, storage):
     assert np.mean(np.abs(a - b) > ulp * np.maximum(np.abs(b), 1e-3 * scale)) < 0.02
 
 
-def test_trained_weights_agree_at_the_north_star_bar():
-    """A network trained by the HIP trainer (ResNet-18 U-Net, 400 steps of cce+Dice on class-coloured blocky
+@pytest.mark.parametrize("storage", ["fp16", "bf16"])
+def test_densenet201_runs_on_both_storage_formats(storage):
+    """DenseNet-201's last conv5 layers read 1824-1888 channels, more than the one-kernel dense layer takes on
+    bf16 storage (1792; 3584 on fp16): those layers must fall back to their two convolutions, the others stay
+    fused, and the network clears its format's bars."""
+    import miseg_amd
+    from miseg_amd import engine, netspec
+    from oracle import nets
+    check_engine("densenet201", "Linknet", (64, 64), 1, 3, storage=storage)
+    g = netspec.build_graph("densenet201", "Linknet", (64, 64, 3), 3)
+    eng = engine.Engine(g, nets.init_weights(nets.build_spec("densenet201", "Linknet", 3), seed=7), batch=1,
+                        storage=storage)
+    kernels = [eng.op_kernel(i) for i in range(eng.num_ops)]
+    fused = kernels.count("dense_layer_kernel")
+    assert fused == (98 if storage == "fp16" else 95), fused      # 6 + 12 + 48 + 32 layers; bf16: the last three apart
+
+
+@pytest.mark.parametrize("enc,hw,steps,block", [("resnet18", (512, 640), 400, 32), ("resnet34", (1920, 2560), 300, 64)])
+def test_trained_weights_agree_at_the_north_star_bar(enc, hw, steps, block):
+    """A network trained by the HIP trainer (U-Net, a few hundred steps of cce+Dice on class-coloured blocky
     masks with noise; /root/reference model_train.py:284-329 is the loop) has the margins of a trained
     network rather than those of seeded random weights: the engine's masks then match the fp32 oracle's on
     >= 99.9 % of all pixels on BOTH storage formats, Dice and IoU within 1e-3 (the bar of the
-    reference-matching target, which the random-weight bf16 run at full size misses)."""
+    reference-matching target, which the random-weight bf16 run at full size misses).  The second case is
+    the headline configuration itself: ResNet-34 U-Net, one fresh 1920x2560 image."""
     import miseg_amd
     from miseg_amd import engine, netspec, trainer, weights as W
     from oracle import nets, ops_torch, post, losses
-    h, w, n, classes, block = 512, 640, 2, 3, 32
+    (h, w), n, classes = hw, 2, 3
     dev = torch.device("cuda:0")
     palette = torch.tensor([[0.15, 0.2, 0.6], [0.8, 0.3, 0.25], [0.45, 0.75, 0.4]], device=dev)
 
@@ -276,18 +295,19 @@ def test_trained_weights_agree_at_the_north_star_bar():
         lo, hi = img.amin(dim=(1, 2, 3), keepdim=True), img.amax(dim=(1, 2, 3), keepdim=True)
         return ((img - lo) / (hi - lo)).contiguous(), torch.nn.functional.one_hot(ids, classes).float(), ids
 
-    g = netspec.build_graph("resnet18", "U-Net", (h, w, 3), classes, "softmax", None)
+    g = netspec.build_graph(enc, "U-Net", (h, w, 3), classes, "softmax", None)
     tr = trainer.Trainer(g, W.init_weights(g, seed=1234), n, loss="cce_dice", learning_rate=1e-3)
     gen = torch.Generator(device=dev).manual_seed(99)
-    for _ in range(400):
+    for _ in range(steps):
         x, gt, _ = batch(gen, n)
         tr.train_step(x, gt)
     wts = tr.get_weights()
     del tr
+    torch.cuda.empty_cache()
     xe, gte, ids = batch(torch.Generator(device=dev).manual_seed(7), 1)
     x_np, gt_np = xe.cpu().numpy(), gte.cpu().numpy()
     with torch.no_grad():
-        want = ops_torch.to_numpy(nets.forward(ops_torch, "resnet18", "U-Net", wts, x_np))
+        want = ops_torch.to_numpy(nets.forward(ops_torch, enc, "U-Net", wts, x_np))
     assert float((want.argmax(-1) == ids.cpu().numpy()).mean()) > 0.95          # it did learn the task
     m_want = np.stack([post.collapse_probabilities(p.copy()) for p in want])
     for storage in ("fp16", "bf16"):
@@ -295,7 +315,8 @@ def test_trained_weights_agree_at_the_north_star_bar():
         got = eng.forward(xe).cpu().numpy()
         agree = float((eng.mask.cpu().numpy() == m_want).all(axis=-1).mean())
         del eng
-        print("%s storage, trained weights: masks agree on %.4f %%" % (storage, 100 * agree))
+        torch.cuda.empty_cache()
+        print("%s %dx%d, %s storage, trained weights: masks agree on %.4f %%" % (enc, h, w, storage, 100 * agree))
         assert agree >= 0.999, (storage, agree)
         assert abs(losses.f1_score(gt_np, got) - losses.f1_score(gt_np, want)) < 1e-3
         assert abs(losses.iou_score(gt_np, got) - losses.iou_score(gt_np, want)) < 1e-3

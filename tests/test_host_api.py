@@ -73,7 +73,7 @@ def test_plan_records_and_validates_without_gpu(pkg):
     # bottleneck ResNets: the two independently written builders (graph, oracle spec) must agree; the
     # totals are what they agree on, not published numbers
     ("resnet50", "U-Net", 52490028), ("resnet101", "Linknet", 50266940), ("resnet152", "FPN", 61648204),
-    ("vgg16", "U-Net", 33494435), ("vgg19", "FPN", 22884547)])
+    ("vgg16", "U-Net", 33476003), ("vgg19", "FPN", 22884547)])
 def test_graph_param_counts_and_oracle_spec(pkg, enc, dec, total):
     from miseg_amd import netspec
     from oracle import nets
@@ -93,10 +93,16 @@ def test_vgg_encoder_parameter_counts(pkg):
         g = netspec.build_graph(enc, "FPN", (64, 64, 3), 3)
         assert sum(g.layers[n].count_params() for n in g.encoder_layers) == total
         assert g.layers[g.encoder_output].cls == "MaxPooling2D"
-        assert [g.layers[n].out.c for n in g.skip_layers] == [512, 512, 256, 128, 64]
-    # U-Net and Linknet put two centre blocks between a pooled encoder output and the decoder
+        # segmentation_models takes Backbones.get_feature_layers(name, n=4): block1_conv2, the fifth layer
+        # its table lists, is not a skip
+        assert [g.layers[n].out.c for n in g.skip_layers] == [512, 512, 256, 128]
+    # U-Net and Linknet put two centre blocks between a pooled encoder output and the decoder; the last
+    # decoder stage has no skip (3x3x32x32 kernel in U-Net, 16 outputs and no Add in Linknet)
     g = netspec.build_graph("vgg16", "U-Net", (64, 64, 3), 3)
-    assert "center_block2_relu" in g.layers and g.layers["decoder_stage4_concat"].out.c == 96
+    assert "center_block2_relu" in g.layers and "decoder_stage4_concat" not in g.layers
+    assert g.layers["decoder_stage4b_conv"].weights[0][1] == (3, 3, 32, 32)
+    g = netspec.build_graph("vgg16", "Linknet", (64, 64, 3), 3)
+    assert g.layers["decoder_stage4c_conv"].weights[0][1] == (1, 1, 32, 16) and "decoder_stage4_add" not in g.layers
 
 
 def test_densenet_skips_resolve_by_keras_index(pkg):

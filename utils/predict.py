@@ -5,6 +5,7 @@ original size, write PNGs.  Decode and PNG encode run on the host (Pillow); ever
 them runs on the GPU.  The OpenCV contour analysis that the reference can chain after the mask
 (`analyze_contours`, `reclassify`, `remove_artifacts`, `use_bias*`) is outside this package.
 """
+import os
 import shutil
 import time
 from pathlib import Path
@@ -46,7 +47,13 @@ def patch_predict(model, image, patch_shape, halo=0):
     of each axis shifted back to end at the border, later patches overwriting earlier ones where
     they overlap; every patch is forwarded without context, so predictions change at patch seams.
     halo > 0 (an option the reference does not have) forwards overlapping windows and keeps only
-    the part of each that lies at least `halo` pixels inside it (see `halo_ranges`)."""
+    the part of each that lies at least `halo` pixels inside it (see `halo_ranges`).
+
+    One deliberate difference: the reference pastes into a buffer hard-coded to 8 channels
+    (/root/reference utils/predict.py:63), which only works for a model with exactly 8 classes (numpy
+    cannot broadcast a (h, w, 3) patch into an (h, w, 8) slice, so its 3-class models raise there).
+    Here the buffer has the model's own number of classes, which is the same result wherever the
+    reference's line runs at all."""
     input_shape = get_model_input_shape(model)
     if tuple(input_shape) != tuple(patch_shape):
         raise ValueError("The model's input shape does not match the patch shape: model '%s' != patch '%s'."
@@ -74,16 +81,10 @@ def patch_predict(model, image, patch_shape, halo=0):
     return out
 
 
-def predict(model, images, normalize=True, input_shape=None, copy_images=False, grayscale=False,
-            analyze_contours=False, output_predictions="predictions", output_contour_analysis=None, bboxes=None,
-            classify_agnor=False, decision_tree_model_path="agnor_classifier.joblib", record_id=None,
-            record_class=None, measures_only=False, current_time=time.strftime("%Y%m%d%H%M%S"),
-            use_bias_layer=False, use_bias=False, reclassify=False, remove_artifacts=False):
-    """Segment one image file or every image of a directory and write `<stem>_prediction.png`
-    (class colours, or class indices with `grayscale`) under `output_predictions`."""
-    if analyze_contours or use_bias or use_bias_layer or reclassify or remove_artifacts or classify_agnor:
-        raise NotImplementedError("contour analysis and Papanicolaou post-processing are OpenCV tooling on the "
-                                  "CPU and are not part of this package; run them on the written masks")
+def files_of_rank(images, shard=None):
+    """The image files this process segments: `images` is one file or a directory; of the sorted,
+    de-duplicated list (/root/reference utils/predict.py:125-131,152) rank r of w takes files r, r + w,
+    r + 2 w, ...  Returns (files, rank, world); `shard=None` reads RANK / WORLD_SIZE."""
     if not isinstance(images, str):
         raise ValueError("`images` must be a `str`. Given `%s`." % type(images))
     if Path(images).is_dir():
@@ -92,7 +93,32 @@ def predict(model, images, normalize=True, input_shape=None, copy_images=False, 
         files = [images]
     else:
         raise FileNotFoundError("The directory or file was not found at `%s`." % images)
+    if shard is None:
+        shard = (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+    rank, world = shard
+    files = sorted(set(str(f) for f in files))
+    return [files[i] for i in _shard.shard_indices(len(files), rank, world)], rank, world
+
+
+def predict(model, images, normalize=True, input_shape=None, copy_images=False, grayscale=False,
+            analyze_contours=False, output_predictions="predictions", output_contour_analysis=None, bboxes=None,
+            classify_agnor=False, decision_tree_model_path="agnor_classifier.joblib", record_id=None,
+            record_class=None, measures_only=False, current_time=time.strftime("%Y%m%d%H%M%S"),
+            use_bias_layer=False, use_bias=False, reclassify=False, remove_artifacts=False, shard=None):
+    """Segment one image file or every image of a directory and write `<stem>_prediction.png`
+    (class colours, or class indices with `grayscale`) under `output_predictions`.
+
+    The reference walks the sorted files one by one on one GPU (/root/reference utils/predict.py:152).
+    Images are independent given the weights, so with one process per GPU each process takes every
+    world-th file of the same sorted list and nothing is exchanged: `shard=(rank, world)`, by default
+    what `torch.distributed.run` left in RANK / WORLD_SIZE (predict.py --gpu 0,1,... starts it)."""
+    if analyze_contours or use_bias or use_bias_layer or reclassify or remove_artifacts or classify_agnor:
+        raise NotImplementedError("contour analysis and Papanicolaou post-processing are OpenCV tooling on the "
+                                  "CPU and are not part of this package; run them on the written masks")
+    files, rank, world = files_of_rank(images, shard)
     if isinstance(model, str):
+        if world > 1 and torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count())
         model = load_model(model_path=model, input_shape=input_shape)
     elif not isinstance(model, _Model):
         raise ValueError("`model` must be a `str` or a model object. Given `%s`." % type(model))
@@ -101,7 +127,7 @@ def predict(model, images, normalize=True, input_shape=None, copy_images=False, 
     out_dir = Path(output_predictions)
     out_dir.mkdir(exist_ok=True, parents=True)
     from PIL import Image
-    for file in sorted(set(files)):
+    for file in files:
         image, original_shape = load_image(image_path=file, normalize=normalize, shape=input_shape[:2],
                                            return_original_shape=True)
         image = image.float()
