@@ -57,6 +57,8 @@ extern "C" {
 #define MISEG_TILE_NO_DMA 16
 #define MISEG_TILE_NO_HALO 32
 #define MISEG_TILE_SHARED_W 64  /* halo kernels: block-shared weight tiles instead of wave-private rings */
+#define MISEG_RES_ADD 0
+#define MISEG_RES_BN_RELU_MASK 1
 #define MISEG_TILE_NO_PERSIST 128 /* Cin = 32 layers and the stem: one patch per block instead of persistent blocks */
 
 const char* miseg_last_error(void);
@@ -158,6 +160,23 @@ typedef struct miseg_conv_desc {
                                  stored 8 channels wide, and the head convolution's data gradient reads it so.
                                  Taken by 3x3 stride-1 layers with Cin = 32, Cout <= 32 and 16-bit output without
                                  residual or second output; MISEG_E_UNSUPPORTED_SHAPE otherwise */
+  int32_t res_mode;           /* MISEG_RES_ADD (0): the residual is added, as described above.
+                                 MISEG_RES_BN_RELU_MASK: this call is the data gradient of a layer that reads
+                                 a = relu(x * scale[c] + shift[c]) (training-mode BatchNormalization + ReLU, the
+                                 pairs classification_models / segmentation_models put in front of their
+                                 convolutions; backward of the model.fit step, model_train.py:284-329).  `residual`
+                                 is x (16-bit, the BatchNormalization's input, at the output's positions), scale /
+                                 shift are the BatchNormalization's forward coefficients and are NOT applied to the
+                                 result.  For output channels c < res_mask_c:
+                                     out = acc  where x * scale[c] + shift[c] > 0,  else 0
+                                 (the gradient behind the ReLU), and `stats`, when given, receives sum(out) in
+                                 [r][0][c] and sum(out * x) in [r][1][c] of the stored values: the two reductions of
+                                 the BatchNormalization's backward pass (miseg_bn_bwd_sums finishes them), which
+                                 then needs no pass of its own over x and the gradient.  Channels from res_mask_c on
+                                 (a skip tensor concatenated behind a) are stored as they are.  Needs 16-bit out
+                                 and residual, Cout % 8 == 0, res_mask_c % 8 == 0, 16-byte aligned strides, no
+                                 activation, no second output */
+  int32_t res_mask_c;
 } miseg_conv_desc;
 
 int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream);
@@ -500,6 +519,14 @@ int miseg_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, int64_t pix
                             const float* scale, const float* shift, const float* mean,
                             const float* var, float eps, int32_t relu, const double* sums,
                             const void* addend, int32_t addend_pix_stride, void* stream);
+
+/* Pass 1 of the above from sums a data-gradient convolution gathered while it wrote g (miseg_conv_desc.res_mode =
+ * MISEG_RES_BN_RELU_MASK; tf.keras computes both in FusedBatchNormGrad, reached from model.fit at
+ * model_train.py:284-329): stats = double[replicas + 1][2][stride] with [r][0][c] = sum g, [r][1][c] = sum g * x.
+ *   sums[c] = sum g, sums[C + c] = (sum g * x - mean[c] * sum g) * rsqrt(var[c] + eps), in fp64.
+ * Pass 2 then runs with relu = 0 on the stored g. */
+int miseg_bn_bwd_sums(const double* stats, int32_t replicas, int32_t stride, int32_t C, const float* mean,
+                      const float* var, float eps, double* sums, void* stream);
 
 /* dx of ZeroPadding2D(1)+MaxPooling2D(3,2): the gradient goes to the first maximum of each
  * window in row-major scan order.  x: pool input [N,H,W,C], dy: [N,H/2,W/2,C], bf16.  addend (may be NULL):

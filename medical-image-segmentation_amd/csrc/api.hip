@@ -39,6 +39,7 @@ int launch_bn_relu_bwd_reduce(const void*, const void*, long long, int, int, int
 int launch_bn_relu_bwd_apply(const void*, const void*, void*, long long, int, int, int, int,
                              const float*, const float*, const float*, const float*, float, int,
                              const double*, const void*, int, hipStream_t);
+int launch_bn_bwd_sums(const double*, int, int, int, const float*, const float*, float, double*, hipStream_t);
 int launch_channel_sums(const void*, long long, int, int, double*, hipStream_t);
 int launch_image_minmax(const void*, int, int, long long, float*, hipStream_t);
 int launch_image_normalize(const void*, int, int, long long, const float*, float*, hipStream_t);
@@ -356,6 +357,10 @@ int miseg_bn_relu_bwd_apply(const void* x, const void* dy, void* dx, int64_t pix
                             int32_t addend_pix_stride, void* stream) {
   return launch_bn_relu_bwd_apply(x, dy, dx, pixels, C, xps, dps, ops, scale, shift, mean, var, eps,
                                   relu, sums, addend, addend_pix_stride, (hipStream_t)stream);
+}
+int miseg_bn_bwd_sums(const double* stats, int32_t replicas, int32_t stride, int32_t C, const float* mean,
+                      const float* var, float eps, double* sums, void* stream) {
+  return launch_bn_bwd_sums(stats, replicas, stride, C, mean, var, eps, sums, (hipStream_t)stream);
 }
 int miseg_image_minmax(const void* img, int32_t dtype, int32_t N, int64_t elems, float* minmax,
                        void* stream) {

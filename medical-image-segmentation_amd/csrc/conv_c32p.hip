@@ -14,11 +14,16 @@
 //  * Epilogue straight from the accumulators (two 16-byte stores per tile complete the 64 bytes
 //    of a pixel); BatchNorm statistics accumulate in registers over all patches of the block and
 //    are flushed once.
+//  * As a data gradient behind relu(bn(x)) (ConvParams::res_mask_c) the patch's x values are requested
+//    right after the next patch's halo, by hand, and awaited by the wait that halo needs anyway: a
+//    load the compiler sees would put a full vmcnt(0) in front of the arithmetic, i.e. behind the
+//    halo prefetch.
 #include "conv_common.h"
 
 namespace MISEG_KNS {
 
 namespace {
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int CP_TH = 8, CP_TW = 32, CP_HWD = CP_TW + 2;
 constexpr int CP_HROWS = (CP_TH + 2) * CP_HWD;     // 340 halo pixels
 constexpr int CP_PITCH = 80;
@@ -38,6 +43,7 @@ __device__ unsigned long long g_cp_prof[4096][8];
 #define CP_TICK(i) do { } while (0)
 #endif
 
+template <bool BNM>
 __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p) {
 #ifdef MISEG_CP_PROFILE
   unsigned long long cp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cp_last = wall_clock64();
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
   if (tid < 64) {
     const int c = tid & 31;
     const float* src = tid < 32 ? p.scale : p.shift;
-    coef[tid] = (src && c < p.Cout) ? src[c] : (tid < 32 ? 1.f : 0.f);
+    coef[tid] = (src && c < (BNM ? p.res_mask_c : p.Cout)) ? src[c] : (tid < 32 ? 1.f : 0.f);
   }
   const unsigned coef_a = lds_a + 2 * CP_HALO_BYTES + lhalf * 32;
   DirectLane dl;
@@ -74,6 +80,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
   dl.c2[1] = 16 + 8 * lhalf;
   dl.okc[0] = dl.c2[0] + 8 <= p.Cout;
   dl.okc[1] = dl.c2[1] + 8 <= p.Cout;
+  dl.okm[0] = BNM && dl.c2[0] + 8 <= p.res_mask_c;
+  dl.okm[1] = BNM && dl.c2[1] + 8 <= p.res_mask_c;
+  constexpr bool bnm = BNM;
   dl.relu = p.act == MISEG_ACT_RELU;
   const bool head = p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID;
   const bool stats = p.stats != nullptr && !head;
@@ -142,6 +151,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
     CP_TICK(0);
     if (tile + nslot < t_end) issue_halo(tile + nslot, cur ^ 1);
     const unsigned xl = xl0 + cur * CP_HALO_BYTES;
+    int n, y0, x0;
+    patch_origin(tile, n, y0, x0);
+    const int ox = x0 + lrow;
+    // x of relu(bn(x)) at this lane's two output pixels, two octets each (lanes without a pixel or an
+    // octet read the zero line, so that every lane's loads count alike)
+    u32x4 xres[2][2];
+    if constexpr (bnm) {
+      static_for<4>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int b = decltype(ic)::value >> 1, q = decltype(ic)::value & 1;
+        const int oy = y0 + 2 * wave + b;
+        const bool ok = oy < p.Ho && ox < p.Wo && dl.okm[q];
+        const h16_t* src = ok ? reinterpret_cast<const h16_t*>(p.residual) + n * p.res_img_stride +
+                                    (long long)oy * p.res_row_stride + (long long)ox * p.res_pix_stride + dl.c2[q]
+                              : reinterpret_cast<const h16_t*>(zero_src);
+        u32x4& dst = xres[b][q];     // (asm operands do not capture by themselves)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+      });
+    }
     CP_TICK(1);
 
     f32x16 acc[2];
@@ -184,7 +211,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
     // the next patch's halo has landed (it had the arithmetic phase, and the other block of the CU
     // was running meanwhile); only then are this patch's stores issued
     CP_TICK(2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (bnm)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(xres[0][0]), "+v"(xres[0][1]), "+v"(xres[1][0]), "+v"(xres[1][1])::"memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     CP_TICK(3);
     {
       h16x8 c[8];
@@ -206,9 +237,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
         dl.sh[4 * i] = b.x; dl.sh[4 * i + 1] = b.y; dl.sh[4 * i + 2] = b.z; dl.sh[4 * i + 3] = b.w;
       }
     }
-    int n, y0, x0;
-    patch_origin(tile, n, y0, x0);
-    const int ox = x0 + lrow;
     const uint4 nores[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     if (head) {
       // softmax / sigmoid head (Cout <= 4, fp32 out): the lower half-wave's first four accumulators are
@@ -231,7 +259,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
         const int oy = y0 + 2 * wave + b;
         const bool okp = oy < p.Ho && ox < p.Wo;
         const long long o_off = n * p.out_img_stride + (long long)oy * p.out_row_stride + (long long)ox * p.out_pix_stride;
-        direct_tile(p, dl, acc[b], okp, okp ? o_off : 0, 0, false, nores, nullptr, st, stats);
+        if constexpr (bnm) {
+          const uint4 xr[2] = {__builtin_bit_cast(uint4, xres[b][0]), __builtin_bit_cast(uint4, xres[b][1])};
+          direct_tile_mask(p, dl, acc[b], okp, okp ? o_off : 0, xr, st, stats);
+        } else {
+          direct_tile(p, dl, acc[b], okp, okp ? o_off : 0, 0, false, nores, nullptr, st, stats);
+        }
       });
     }
     CP_TICK(4);
@@ -279,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
 // The layers this kernel takes over from conv3x3_c32_kernel: bf16 output whose 8-channel groups can be
 // stored as 16 bytes, or the softmax / sigmoid head (fp32 out, Cout <= 4); no residual, no second output.
 bool conv_c32p_ok(const ConvParams& p) {
-  if (p.residual || p.out2 || !p.out) return false;
+  if ((p.residual && !p.res_mask_c) || p.out2 || !p.out) return false;
   if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID)
     return p.out_dtype == MISEG_DT_F32 && p.Cout <= 4 && !p.stats;
   return p.vec_ok && p.out_dtype == MISEG_DT_BF16 && (p.Cout & 7) == 0;
@@ -289,7 +322,10 @@ hipError_t launch_conv_c32p(const ConvParams& p, hipStream_t s) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int blocks = p.mtiles < 2 * cus ? p.mtiles : 2 * cus;
-  hipLaunchKernelGGL(conv3x3_c32p_kernel, dim3(blocks), dim3(256), 0, s, p);
+  if (p.res_mask_c && !MISEG_BUILD_F16)
+    hipLaunchKernelGGL(conv3x3_c32p_kernel<!MISEG_BUILD_F16>, dim3(blocks), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(conv3x3_c32p_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 

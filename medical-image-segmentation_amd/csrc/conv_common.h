@@ -61,6 +61,9 @@ struct ConvParams {
   int res_after;         // the residual is added after the activation (out = act(v) + residual)
   int dgrad_t;           // data gradient of Conv2DTranspose(4, 2): `in` is dY, taps run over its four phase lattices
   int in_valid_c;        // channels of an input pixel that exist in memory (the rest read as zero); Cin when all do
+  int res_mask_c;        // > 0: MISEG_RES_BN_RELU_MASK -- `residual` is x, scale/shift are the BatchNorm's forward
+                         // coefficients (not applied); couts below res_mask_c are zeroed where x * scale + shift <= 0
+                         // and the statistics are sum(out), sum(out * x); 0: the residual is added
 };
 
 // 16 zero bytes x 8: the source of LDS-DMA loads for taps that fall outside the image.
@@ -189,7 +192,7 @@ struct LinearDecode {
   }
 };
 
-template <int WARPS_N, int MT, int NT, class Decode>
+template <int WARPS_N, int MT, int NT, class Decode, bool BNM = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoord& tc,
                                               const Decode& decode, f32x16 (&acc)[NT][MT],
                                               unsigned char* lds, int wm, int wn, int lane,
@@ -203,7 +206,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
   float* ep = reinterpret_cast<float*>(lds) + wave * (32 * ROWF);
   const int lrow = lane & 31, lhalf = lane >> 5;
   const int HoWo = p.Ho * p.Wo;
-  const bool has_res = p.residual != nullptr;
+  const bool has_res = p.residual != nullptr && !BNM;
   const int px_l = lane / LPP;
   const int co_l = (lane % LPP) * 8;
   const int co = tc.cout0 + wn * TNW + co_l;
@@ -262,6 +265,40 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
                                (long long)ox * p.out2_pix_stride + cox;
       const long long r_off = n * p.res_img_stride + (long long)(oy >> p.res_shift) * p.res_row_stride +
                               (long long)(ox >> p.res_shift) * p.res_pix_stride + cox;
+      if constexpr (BNM) {
+        // data gradient behind relu(bn(x)) (ConvParams::res_mask_c; full, aligned channel groups are guaranteed
+        // by the launcher): mask with the sign of x * scale + shift, reduce sum(g), sum(g * x)
+        if (!fullx) continue;
+        uint4 pk = make_uint4(pack_h16x2_raw(v[0], v[1]), pack_h16x2_raw(v[2], v[3]), pack_h16x2_raw(v[4], v[5]),
+                              pack_h16x2_raw(v[6], v[7]));
+        if (cox + 8 <= p.res_mask_c) {
+          const uint4 r = *reinterpret_cast<const uint4*>(reinterpret_cast<const h16_t*>(p.residual) + r_off);
+          const float xr[8] = {h16lo_to_f32(r.x), h16hi_to_f32(r.x), h16lo_to_f32(r.y), h16hi_to_f32(r.y),
+                               h16lo_to_f32(r.z), h16hi_to_f32(r.z), h16lo_to_f32(r.w), h16hi_to_f32(r.w)};
+          const float4 s0 = *reinterpret_cast<const float4*>(p.scale + cox);
+          const float4 s1 = *reinterpret_cast<const float4*>(p.scale + cox + 4);
+          const float4 t0 = *reinterpret_cast<const float4*>(p.shift + cox);
+          const float4 t1 = *reinterpret_cast<const float4*>(p.shift + cox + 4);
+          const float sc8[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+          const float sh8[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (xr[j] * sc8[j] + sh8[j] <= 0.f) v[j] = 0.f;
+          pk = make_uint4(pack_h16x2_raw(v[0], v[1]), pack_h16x2_raw(v[2], v[3]), pack_h16x2_raw(v[4], v[5]),
+                          pack_h16x2_raw(v[6], v[7]));
+          if (p.stats) {
+            const float g8[8] = {h16lo_to_f32(pk.x), h16hi_to_f32(pk.x), h16lo_to_f32(pk.y), h16hi_to_f32(pk.y),
+                                 h16lo_to_f32(pk.z), h16hi_to_f32(pk.z), h16lo_to_f32(pk.w), h16hi_to_f32(pk.w)};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              st_s[j] += g8[j];
+              st_q[j] += g8[j] * xr[j];
+            }
+          }
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + o_off) = pk;
+        continue;
+      }
       if (fullx) {
         if (p.scale) {
           const float4 s0 = *reinterpret_cast<const float4*>(p.scale + cox);
@@ -448,6 +485,7 @@ __device__ __forceinline__ void load_coef8(const float* src, int c, int Cout, fl
 struct DirectLane {
   int c2[2];          // first cout of each octet
   bool okc[2];        // octet inside Cout
+  bool okm[2];        // MISEG_RES_BN_RELU_MASK: octet below res_mask_c (masked and reduced)
   float sc[16], sh[16];
   bool relu;
 };
@@ -455,6 +493,9 @@ struct DirectLane {
 struct DirectOut2 {
   float s2[16], t2[16];
 };
+// BNM: the launch is a data gradient behind relu(bn(x)) (ConvParams::res_mask_c); a compile-time switch, so
+// that the kernels' other instantiations carry none of it.
+template <bool BNM = false>
 __device__ __forceinline__ void direct_lane_init(const ConvParams& p, int cbase, int lane, DirectLane& d) {
   const int lhalf = lane >> 5;
   d.c2[0] = cbase + 8 * lhalf;
@@ -463,8 +504,11 @@ __device__ __forceinline__ void direct_lane_init(const ConvParams& p, int cbase,
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     d.okc[q] = d.c2[q] + 8 <= p.Cout;
-    load_coef8(p.scale, d.c2[q], p.Cout, d.sc + 8 * q, 1.f);
-    load_coef8(p.shift, d.c2[q], p.Cout, d.sh + 8 * q, 0.f);
+    d.okm[q] = BNM && d.c2[q] + 8 <= p.res_mask_c;
+    // (as a BatchNorm-ReLU mask the vectors hold res_mask_c entries only)
+    const int ncoef = BNM ? p.res_mask_c : p.Cout;
+    load_coef8(p.scale, d.c2[q], ncoef, d.sc + 8 * q, 1.f);
+    load_coef8(p.shift, d.c2[q], ncoef, d.sh + 8 * q, 0.f);
   }
 }
 __device__ __forceinline__ void direct_out2_init(const ConvParams& p, const DirectLane& d, DirectOut2& o) {
@@ -473,6 +517,51 @@ __device__ __forceinline__ void direct_out2_init(const ConvParams& p, const Dire
     load_coef8(p.scale2, d.c2[q], p.Cout, o.s2 + 8 * q, 1.f);
     load_coef8(p.shift2, d.c2[q], p.Cout, o.t2 + 8 * q, 0.f);
   }
+}
+
+// The same for the data gradient behind relu(bn(x)) (ConvParams::res_mask_c): `res` holds x, d.sc / d.sh the
+// BatchNorm's forward coefficients; octet by octet, so that x lives in registers only while its octet is finished.
+__device__ __forceinline__ void direct_tile_mask(const ConvParams& p, const DirectLane& d, const f32x16& a, bool okp,
+                                                 long long o_off, const uint4 (&res)[2], float* st, bool do_stats) {
+  float v[16];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[8 * q + r]),
+                                                       __float_as_uint(a[8 * q + 4 + r]), false, false);
+      v[8 * q + r] = __uint_as_float(sw[0]);
+      v[8 * q + 4 + r] = __uint_as_float(sw[1]);
+    }
+  static_for<2>([&](auto qc) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value;
+    if (okp && d.okc[q]) {
+      float xr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = v[8 * q + j];
+      if (d.okm[q]) {
+        const uint4 r = res[q];
+        xr[0] = h16lo_to_f32(r.x); xr[1] = h16hi_to_f32(r.x); xr[2] = h16lo_to_f32(r.y); xr[3] = h16hi_to_f32(r.y);
+        xr[4] = h16lo_to_f32(r.z); xr[5] = h16hi_to_f32(r.z); xr[6] = h16lo_to_f32(r.w); xr[7] = h16hi_to_f32(r.w);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          w[j] = xr[j] * d.sc[8 * q + j] + d.sh[8 * q + j] <= 0.f ? 0.f : w[j];
+      }
+      const uint4 pk = make_uint4(pack_h16x2_raw(w[0], w[1]), pack_h16x2_raw(w[2], w[3]), pack_h16x2_raw(w[4], w[5]),
+                                  pack_h16x2_raw(w[6], w[7]));
+      *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + o_off + d.c2[q]) = pk;
+      if (do_stats && d.okm[q]) {
+        const float g[8] = {h16lo_to_f32(pk.x), h16hi_to_f32(pk.x), h16lo_to_f32(pk.y), h16hi_to_f32(pk.y),
+                            h16lo_to_f32(pk.z), h16hi_to_f32(pk.z), h16lo_to_f32(pk.w), h16hi_to_f32(pk.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          st[8 * q + j] += g[j];
+          st[16 + 8 * q + j] += g[j] * xr[j];
+        }
+      }
+    }
+  });
 }
 
 // One 32x32 accumulator tile -> memory.  EVERY lane of the wave must call this (the swaps are
@@ -548,7 +637,7 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
 }
 
 // All MT pixel rows of a wave (pixel index = wm * MT * 32 + b * 32 + lane % 32 through `decode`).
-template <int MT, class Decode>
+template <int MT, class Decode, bool BNM = false>
 __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const TileCoord& tc,
                                                      const Decode& decode, f32x16 (&acc)[MT],
                                                      int wm, int lane, const DirectLane& d,
@@ -580,14 +669,17 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const 
                                 (long long)(ox >> p.res_shift) * p.res_pix_stride;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-          res[i][q] = okp[i] && d.okc[q]
+          res[i][q] = okp[i] && d.okc[q] && (!BNM || d.okm[q])
                           ? *reinterpret_cast<const uint4*>(reinterpret_cast<const h16_t*>(p.residual) + r_off + d.c2[q])
                           : make_uint4(0, 0, 0, 0);
       }
     }
     static_for<RG>([&](auto ic) __attribute__((always_inline)) {
       constexpr int i = decltype(ic)::value;
-      direct_tile(p, d, acc[b0 + i], okp[i], o_off[i], o2_off[i], has_res, res[i], p.out2 ? &o2 : nullptr, st, do_stats);
+      if constexpr (BNM)
+        direct_tile_mask(p, d, acc[b0 + i], okp[i], o_off[i], res[i], st, do_stats);
+      else
+        direct_tile(p, d, acc[b0 + i], okp[i], o_off[i], o2_off[i], has_res, res[i], p.out2 ? &o2 : nullptr, st, do_stats);
     });
   });
 }
@@ -595,7 +687,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const 
 // A wave tile of NT cout groups: group a covers couts [cbase + 32 a, cbase + 32 a + 32).  BNB =
 // couts per block (for the statistics' block-level sums in `lds`, which every wave of the block
 // must reach).
-template <int MT, int NT, int BNB, class Decode>
+template <int MT, int NT, int BNB, class Decode, bool BNM = false>
 __device__ __forceinline__ void conv_epilogue_direct_groups(const ConvParams& p, const TileCoord& tc,
                                                             const Decode& decode, f32x16 (&acc)[NT][MT],
                                                             int wm, int cbase, int lane, unsigned char* lds) {
@@ -607,8 +699,8 @@ __device__ __forceinline__ void conv_epilogue_direct_groups(const ConvParams& p,
     for (int j = 0; j < 32; ++j) st[a][j] = 0.f;
     if (cbase + a * 32 < p.Cout) {
       DirectLane dl;
-      direct_lane_init(p, cbase + a * 32, lane, dl);
-      conv_epilogue_direct<MT>(p, tc, decode, acc[a], wm, lane, dl, st[a], stats);
+      direct_lane_init<BNM>(p, cbase + a * 32, lane, dl);
+      conv_epilogue_direct<MT, Decode, BNM>(p, tc, decode, acc[a], wm, lane, dl, st[a], stats);
     }
   });
   if (stats) {

@@ -57,7 +57,7 @@ __device__ unsigned long long g_pw_prof[1 << 16][4];
 #define PW_TICK(i) do { } while (0)
 #endif
 
-template <int WARPS_M, int MT, bool CONVT, bool DGT = false>
+template <int WARPS_M, int MT, bool CONVT, bool DGT = false, bool BNM = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParams p) {
   static_assert(!(CONVT && DGT), "one mode");
 #ifdef MISEG_PW_PROFILE
@@ -273,6 +273,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
 #undef MISEG_DS_READ
 #undef MISEG_LGKM_WAIT
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+  if constexpr (BNM) {
+    // data gradient behind relu(bn(x)): the masked form of the same epilogue (the launcher checked its conditions)
+    conv_epilogue_direct_groups<MT, 1, BN, PatchDecode<TH, TW>, true>(p, tc, dec, acc, wm, tc.cout0 + cgrp * 32, lane, lds);
+    return;
+  }
   if (direct_epilogue_ok(p)) {
     // straight from the accumulators: no LDS, no waits between the rows' stores
     conv_epilogue_direct_groups<MT, 1, BN>(p, tc, dec, acc, wm, tc.cout0 + cgrp * 32, lane, lds);
@@ -303,6 +308,7 @@ constexpr int KS_WST = 32 * 64;   // one ring slot: [32 couts][32 k] bf16
 static_assert(PW_HALO_BYTES + 4 * 4 * KS_WST == PW_LDS, "same LDS budget as the full-K kernel");
 }  // namespace
 
+template <bool BNM = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_ks_kernel(const ConvParams p) {
   constexpr int TH = PW_TH, TW = PW_TW, HWD = PW_HWD, PITCH = PW_PITCH, MT = 8;
   constexpr int TAPS = 9, TAPW = 3;
@@ -498,6 +504,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_ks_kernel(const ConvParam
   }
   f32x16 fin[1][4] = {{acc[0][0], acc[0][1], acc[0][2], acc[0][3]}};
   const PatchDecode<TH, TW> dec{n, y0, x0, p.Ho, p.Wo};
+  if constexpr (BNM) {
+    __syncthreads();   // the statistics' block sums alias the swap regions
+    conv_epilogue_direct_groups<4, 1, BN, PatchDecode<TH, TW>, true>(p, tc, dec, fin, kh, tc.cout0 + wn * 32, lane, lds);
+    return;
+  }
   if (direct_epilogue_ok(p)) {
     __syncthreads();   // the statistics' block sums alias the swap regions
     conv_epilogue_direct_groups<4, 1, BN>(p, tc, dec, fin, kh, tc.cout0 + wn * 32, lane, lds);
@@ -746,16 +757,26 @@ hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s) {
     hipLaunchKernelGGL(convT_c64_kernel, dim3(blocks), dim3(256), 0, s, p);
     return hipGetLastError();
   }
+  // data gradients behind relu(bn(x)) (res_mask_c; validate_conv guarantees what the direct epilogue needs):
+  // instantiations of their own, so that the others carry nothing of the mask
   if (!p.transposed && !p.dgrad_t && p.Cout <= 64) {
-    hipLaunchKernelGGL(conv3x3_halo_ks_kernel, grid, dim3(256), 0, s, p);
+    if (p.res_mask_c && !MISEG_BUILD_F16)
+      hipLaunchKernelGGL(conv3x3_halo_ks_kernel<!MISEG_BUILD_F16>, grid, dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL(conv3x3_halo_ks_kernel<false>, grid, dim3(256), 0, s, p);
     return hipGetLastError();
   }
   if (p.dgrad_t) {
-    hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, true>), grid, dim3(256), 0, s, p);
+    if (p.res_mask_c && !MISEG_BUILD_F16)
+      hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, true, !MISEG_BUILD_F16>), grid, dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, true>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
   }
   if (p.transposed)
     hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, true>), grid, dim3(256), 0, s, p);
+  else if (p.res_mask_c && !MISEG_BUILD_F16)
+    hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, false, !MISEG_BUILD_F16>), grid, dim3(256), 0, s, p);
   else
     hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false>), grid, dim3(256), 0, s, p);
   return hipGetLastError();

@@ -22,7 +22,7 @@ namespace MISEG_KNS {
 // Kernel A: register-staged, BK = 32.  Serves operands that need the BatchNorm+ReLU
 // prologue and layers whose Cin is not a multiple of 64.
 // ---------------------------------------------------------------------------------
-template <int WARPS_M, int WARPS_N, int MT, int NT, bool PRO>
+template <int WARPS_M, int WARPS_N, int MT, int NT, bool PRO, bool BNM = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) {
   constexpr int BM = WARPS_M * MT * 32;
   constexpr int BN = WARPS_N * NT * 32;
@@ -168,6 +168,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
     __syncthreads();
   }
   const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
+  if constexpr (BNM) {
+    // data gradient behind relu(bn(x)): the masking form of the LDS epilogue
+    __syncthreads();
+    conv_epilogue<WARPS_N, MT, NT, LinearDecode, true>(p, tc, dec, acc, lds, wm, wn, lane);
+    return;
+  }
   if (p.direct && direct_epilogue_ok(p)) {
     // large, bandwidth-bound launches (full-resolution 1x1 layers): no LDS round trip, no waits
     // between the rows' stores; short launches are faster through the LDS form
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvParams p) 
 // Taps outside the image read a line of zeros instead.  Tile k+1 is in flight while the
 // MFMAs of tile k run; one vmcnt(0) + barrier per K-step.
 // ---------------------------------------------------------------------------------
-template <int WARPS_M, int WARPS_N, int MT, int NT>
+template <int WARPS_M, int WARPS_N, int MT, int NT, bool BNM = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const ConvParams p) {
   constexpr int BM = WARPS_M * MT * 32;
   constexpr int BN = WARPS_N * NT * 32;
@@ -316,6 +322,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_dma_kernel(const ConvParams
     compute(ks & 1);
   }
   const LinearDecode dec{tc.m0, p.M, HoWo, p.Wo};
+  if constexpr (BNM) {
+    // data gradient behind relu(bn(x)): the masking form of the LDS epilogue
+    __syncthreads();
+    conv_epilogue<WARPS_N, MT, NT, LinearDecode, true>(p, tc, dec, acc, lds, wm, wn, lane);
+    return;
+  }
   if (p.direct && direct_epilogue_ok(p)) {
     // large, bandwidth-bound launches (full-resolution 1x1 layers): no LDS round trip, no waits
     // between the rows' stores; short launches are faster through the LDS form
@@ -646,6 +658,16 @@ static const TileCfg kCfgs[] = {
 
 template <int WM, int WN, int MT, int NT>
 static hipError_t launch_cfg(const ConvParams& p, dim3 grid, bool pro, bool dma, hipStream_t s) {
+#if !MISEG_BUILD_F16
+  // data gradients behind relu(bn(x)) (training runs on bf16 storage): instantiations of their own
+  if (p.res_mask_c && !pro) {
+    if (dma)
+      hipLaunchKernelGGL((conv_igemm_dma_kernel<WM, WN, MT, NT, true>), grid, dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, false, true>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+  }
+#endif
   if (pro)
     hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, true>), grid, dim3(256), 0, s, p);
   else if (dma)
@@ -753,9 +775,26 @@ int validate_conv(const miseg_conv_desc* d) {
     MISEG_CHECK_ARG(((uintptr_t)d->in_scale & 15) == 0 && ((uintptr_t)d->in_shift & 15) == 0,
                     "conv: prologue vectors must be 16-byte aligned");
   }
+  MISEG_CHECK_ARG(d->res_mode == MISEG_RES_ADD || d->res_mode == MISEG_RES_BN_RELU_MASK, "conv: unknown res_mode %d",
+                  (int)d->res_mode);
+  if (d->res_mode == MISEG_RES_BN_RELU_MASK) {
+    MISEG_CHECK_ARG(d->residual && d->res_dtype == MISEG_DT_BF16 && d->scale && d->shift && d->out &&
+                        d->out_dtype == MISEG_DT_BF16 && !d->out2 && d->act == MISEG_ACT_NONE && !d->res_after_act &&
+                        !d->res_upsample_shift,
+                    "conv: the BatchNorm-ReLU mask needs x as a 16-bit residual, scale and shift, a 16-bit output, "
+                    "no activation and no second output");
+    MISEG_CHECK_ARG(d->transposed != 1, "conv: the BatchNorm-ReLU mask is for data gradients, not for transpose convolutions");
+    MISEG_CHECK_ARG(d->res_mask_c > 0 && (d->res_mask_c & 7) == 0 && d->res_mask_c <= d->Cout && (d->Cout & 7) == 0,
+                    "conv: res_mask_c must be a positive multiple of 8, at most Cout (a multiple of 8)");
+    MISEG_CHECK_ARG((d->out_pix_stride & 7) == 0 && (d->out_row_stride & 7) == 0 && (d->out_img_stride & 7) == 0 &&
+                        ((uintptr_t)d->out & 15) == 0 && (d->res_pix_stride & 7) == 0 && (d->res_row_stride & 7) == 0 &&
+                        (d->res_img_stride & 7) == 0 && ((uintptr_t)d->residual & 15) == 0,
+                    "conv: the BatchNorm-ReLU mask needs 16-byte aligned output and residual strides");
+  }
   if (d->stats) {
+    const int stat_c = d->res_mode == MISEG_RES_BN_RELU_MASK ? d->res_mask_c : d->Cout;
     MISEG_CHECK_ARG(d->out && d->out_dtype == MISEG_DT_BF16 && (d->Cout & 7) == 0 && d->stats_replicas > 0 &&
-                        d->stats_stride >= d->Cout && ((uintptr_t)d->stats & 7) == 0,
+                        d->stats_stride >= stat_c && ((uintptr_t)d->stats & 7) == 0,
                     "conv: stats need a bf16 output, Cout % 8 == 0, replicas > 0, stride >= Cout");
     MISEG_CHECK_ARG((d->out_pix_stride & 7) == 0 && (d->out_row_stride & 7) == 0 && (d->out_img_stride & 7) == 0 &&
                         ((uintptr_t)d->out & 15) == 0 && !d->out2 &&
@@ -788,7 +827,7 @@ hipError_t launch_conv_pw_thin(ConvParams p, hipStream_t s);
 // short-contraction 1x1 layers go to the persistent point-wise kernel (MISEG_NO_PW_THIN keeps them on the tiles)
 static bool pw_thin_wanted(const miseg_conv_desc* d, const ConvParams& p, KernelKind kind) {
   static const bool off = getenv("MISEG_NO_PW_THIN") != nullptr;
-  return !off && kind == K_DMA && (d->tile_hint & 15) == 0 && conv_pw_thin_ok(p);
+  return !off && kind == K_DMA && (d->tile_hint & 15) == 0 && !p.res_mask_c && conv_pw_thin_ok(p);
 }
 struct KernelChoice {
   KernelKind kind;
@@ -926,6 +965,7 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
   p.res_shift = d->res_upsample_shift;
   p.out2_linear = d->out2_linear ? 1 : 0;
   p.in_valid_c = d->in_valid_c > 0 ? d->in_valid_c : d->Cin;
+  p.res_mask_c = d->res_mode == MISEG_RES_BN_RELU_MASK ? d->res_mask_c : 0;
   // one million output pixels, or 64 million output values: from there on the epilogue's HBM traffic, not its
   // latency, is what a generic launch waits for (measured on the full-resolution 1x1 layers of LinkNet and FPN:
   // 1.1-2.2x faster; LinkNet's 416 -> 640 layer at 120x160x8)
@@ -956,6 +996,10 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     set_error("conv: in_valid_c needs a 3x3 stride-1 layer with Cin = 32, Cout <= 32, 16-bit output, no residual");
     return MISEG_E_UNSUPPORTED_SHAPE;
   }
+  if (p.res_mask_c && (MISEG_BUILD_F16 || !p.vec_ok)) {
+    set_error("conv: the BatchNorm-ReLU mask needs bf16 storage and 16-byte aligned tensors");
+    return MISEG_E_UNSUPPORTED_SHAPE;
+  }
   if (d->transposed == MISEG_CONV_DGRAD_T) {
     // dX = sum over the four phase lattices of dY: one launch of the ring kernel in its data-gradient mode
     p.transposed = 0;
@@ -975,6 +1019,17 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   const int cfg = kc.cfg;
   const bool pro = kc.kind == K_REG_PRO;
   const bool dma = kc.kind == K_DMA;
+  if (p.res_mask_c) {
+    // the BatchNorm-ReLU mask exists in the ring kernels, the persistent 32-channel kernel and the generic tiles
+    // (bf16 storage); a layer that would run elsewhere is declined, and the caller runs the two passes instead
+    const bool tiles = (kc.kind == K_REG || kc.kind == K_DMA) && cfg >= 1 && cfg <= 7 && !MISEG_BUILD_F16;
+    const bool ring = kc.kind == K_HALO_PW && !d->transposed && !MISEG_BUILD_F16;
+    const bool c32p = kc.kind == K_C32 && conv_c32p_ok(p) && !(d->tile_hint & MISEG_TILE_NO_PERSIST) && !MISEG_BUILD_F16;
+    if (!(tiles || ring || c32p) || !p.vec_ok) {
+      set_error("conv: the BatchNorm-ReLU mask is not built for the kernel this layer runs on");
+      return MISEG_E_UNSUPPORTED_SHAPE;
+    }
+  }
   p.tiles_y = p.tiles_x = 0;
   if (kc.kind == K_C32) {
     p.tiles_y = (d->Ho + 7) / 8;

@@ -402,6 +402,48 @@ __global__ void bn_relu_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf1
   }
 }
 
+// The two reductions of the backward pass from what a data-gradient epilogue gathered
+// (MISEG_RES_BN_RELU_MASK): stats[r][0][c] = sum(g), stats[r][1][c] = sum(g * x) over the block's pixels, g
+// the gradient behind the ReLU.  sums[c] = sum(g) (the beta gradient), sums[C + c] = sum(g * xhat) =
+// (sum(g * x) - mean * sum(g)) / sqrt(var + eps) (the gamma gradient), in fp64.
+__global__ __launch_bounds__(64 * FIN_RG) void bn_bwd_sums_kernel(const double* __restrict__ stats, int replicas,
+                                                                  int stride, int C, const float* __restrict__ mean,
+                                                                  const float* __restrict__ var, float eps,
+                                                                  double* __restrict__ sums) {
+  __shared__ double part[FIN_RG][2][64];
+  const int lc = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = rg; r < replicas; r += FIN_RG) {
+      s1 += stats[((long long)r * 2 + 0) * stride + c];
+      s2 += stats[((long long)r * 2 + 1) * stride + c];
+    }
+  }
+  part[rg][0][lc] = s1;
+  part[rg][1][lc] = s2;
+  __syncthreads();
+  if (rg != 0 || c >= C) return;
+#pragma unroll
+  for (int i = 1; i < FIN_RG; ++i) {
+    s1 += part[i][0][lc];
+    s2 += part[i][1][lc];
+  }
+  sums[c] = s1;
+  sums[C + c] = (s2 - (double)mean[c] * s1) / sqrt((double)var[c] + (double)eps);
+}
+
+int launch_bn_bwd_sums(const double* stats, int replicas, int stride, int C, const float* mean, const float* var,
+                       float eps, double* sums, hipStream_t s) {
+  MISEG_CHECK_ARG(stats && mean && var && sums, "bn_bwd_sums: null pointer");
+  MISEG_CHECK_ARG(replicas > 0 && C > 0 && stride >= C, "bn_bwd_sums: needs replicas > 0 and 0 < C <= stride");
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3((C + 63) / 64), dim3(64 * FIN_RG), 0, s, stats, replicas, stride, C,
+                     mean, var, eps, sums);
+  MISEG_CHECK_HIP(hipGetLastError());
+  return MISEG_OK;
+}
+
 static int check_bn_bwd(const void* x, const void* dy, long long pixels, int C, int xps, int dps) {
   MISEG_CHECK_ARG(x && dy, "bn_relu_bwd: null pointer");
   MISEG_CHECK_ARG(pixels > 0 && C > 0 && (C & 7) == 0 && (xps & 7) == 0 && (dps & 7) == 0 &&

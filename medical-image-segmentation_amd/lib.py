@@ -16,6 +16,7 @@ DT_BF16, DT_F32 = 0, 1
 FMT_BF16, FMT_F16 = 0, 1      # 16-bit storage format of activations and weights (miseg_conv_desc.fmt)
 ACT_NONE, ACT_RELU, ACT_SOFTMAX, ACT_SIGMOID = 0, 1, 2, 3
 LOSS_CCE, LOSS_DICE, LOSS_FOCAL = 1, 2, 4
+RES_ADD, RES_BN_RELU_MASK = 0, 1
 
 
 class MisegError(RuntimeError):
@@ -44,6 +45,7 @@ class ConvDesc(C.Structure):
         ("fmt", C.c_int32), ("res_after_act", C.c_int32), ("res_upsample_shift", C.c_int32),
         ("out2_linear", C.c_int32),
         ("in_valid_c", C.c_int32),
+        ("res_mode", C.c_int32), ("res_mask_c", C.c_int32),
     ]
 
 
@@ -142,6 +144,7 @@ SIGNATURES = {
                                         _FP, _VP, _VP]),
     "miseg_bn_relu_bwd_reduce": (C.c_int, [_VP, _VP, _I64, _I32, _I32, _I32, _FP, _FP, _FP, _FP,
                                            C.c_float, _I32, _VP, _VP]),
+    "miseg_bn_bwd_sums": (C.c_int, [_VP, _I32, _I32, _I32, _FP, _FP, C.c_float, _VP, _VP]),
     "miseg_bn_relu_bwd_apply": (C.c_int, [_VP, _VP, _VP, _I64, _I32, _I32, _I32, _I32, _FP, _FP, _FP,
                                           _FP, C.c_float, _I32, _VP, _VP, _I32, _VP]),
     "miseg_maxpool3x3s2_bwd": (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _I32, _I32, _VP, _I32, _VP]),

@@ -617,10 +617,13 @@ class Trainer:
 
     def conv(self, x, wptr, cout, kh, kw, sy, sx, py, px, out, ho, wo, bias=None, transposed=False,
              out_view=None, act=L.ACT_NONE, probs=None, temperature=1.0, residual=None, stats=None,
-             in_valid_c=0):
+             in_valid_c=0, bn_mask=None):
         """out_view: (ptr, pix, row, img) to address a strided lattice; default = dense `out`.
         stats: zeroed fp64 buffer of (STAT_REPLICAS + 1) * 2 * _c32(cout) entries that receives the
-        per-channel sum and sum of squares of the stored output (for a following BatchNormalization)."""
+        per-channel sum and sum of squares of the stored output (for a following BatchNormalization).
+        bn_mask: (x, scale, shift, channels, stats) -- this call is the data gradient of the layer that reads
+        relu(x * scale + shift): its first `channels` outputs are zeroed where the ReLU was inactive and their
+        sums for the BatchNormalization's backward pass go to `stats` (miseg_conv_desc.res_mode)."""
         d = L.ConvDesc()
         d.inp, d.weight = x.ptr, wptr
         d.N, d.H, d.W, d.Cin = x.n, x.h, x.w, _c32(x.c)
@@ -649,6 +652,14 @@ class Trainer:
             r = residual
             d.residual, d.res_dtype = r.ptr, L.DT_BF16
             d.res_pix_stride, d.res_row_stride, d.res_img_stride = r.pix, r.pix * r.w, r.pix * r.w * r.h
+        if bn_mask is not None:
+            assert residual is None and bias is None and stats is None
+            bx, bscale, bshift, bc, bstats, _ = bn_mask
+            d.residual, d.res_dtype = bx.ptr, L.DT_BF16
+            d.res_pix_stride, d.res_row_stride, d.res_img_stride = bx.pix, bx.pix * bx.w, bx.pix * bx.w * bx.h
+            d.scale, d.shift = bscale, bshift
+            d.res_mode, d.res_mask_c = L.RES_BN_RELU_MASK, bc
+            stats = (bstats.data_ptr(), _c32(bc))
         d.act = act
         d.transposed = int(transposed)          # True/1: transpose conv; 2: its data gradient
         d.temperature = temperature
@@ -656,6 +667,14 @@ class Trainer:
             d.stats, d.stats_replicas, d.stats_stride = stats[0], STAT_REPLICAS, stats[1]
         elif stats is not None:
             d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), STAT_REPLICAS, _c32(cout)
+        if bn_mask is not None:
+            # the mask is built into the kernels the large layers run on; a layer on another kernel declines
+            self._note_conv(d, x, False, True)
+            rc = self.lib.miseg_conv2d_fwd(C.byref(d), self.stream())
+            if rc == L.E_UNSUPPORTED_SHAPE:
+                return False
+            L.check(rc)
+            return True
         self._note_conv(d, x, probs is not None, residual is not None)
         L.check(self.lib.miseg_conv2d_fwd(C.byref(d), self.stream()))
 
@@ -1188,6 +1207,8 @@ class Trainer:
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream(self.dev))
         grads = {}
+        self.bwd_fused = set()        # BatchNormalizations whose backward sums a data gradient's epilogue gathers
+        self.bwd_masked = {}          # layer -> leading channels of its data gradient that carry the ReLU's mask
         self.grad_log = {} if self.keep_grads else None
         self.accum_log, self.accum_final = {}, {}
         c = self.classes
@@ -1249,16 +1270,23 @@ class Trainer:
                 s = self.bn_state[name]
                 cc = l.out.c
                 sums = torch.empty(2 * cc, dtype=torch.float64, device=self.dev)
-                L.check(lib.miseg_bn_relu_bwd_reduce(xin.ptr, dy.ptr, xin.pixels, cc, xin.pix, dy.pix,
-                                                     s["scale"].data_ptr(), s["shift"].data_ptr(),
-                                                     s["mean"].data_ptr(), s["var"].data_ptr(),
-                                                     l.config["epsilon"], 1, sums.data_ptr(), st))
-                def run(res, xin=xin, s=s, cc=cc, sums=sums, dy=dy, eps=l.config["epsilon"]):
+                masked = name in self.bwd_fused
+                if masked:
+                    # dy is already the gradient behind the ReLU and its sums came with it
+                    L.check(lib.miseg_bn_bwd_sums(s["fused"].data_ptr(), STAT_REPLICAS, _c32(cc), cc,
+                                                  s["mean"].data_ptr(), s["var"].data_ptr(), l.config["epsilon"],
+                                                  sums.data_ptr(), st))
+                else:
+                    L.check(lib.miseg_bn_relu_bwd_reduce(xin.ptr, dy.ptr, xin.pixels, cc, xin.pix, dy.pix,
+                                                         s["scale"].data_ptr(), s["shift"].data_ptr(),
+                                                         s["mean"].data_ptr(), s["var"].data_ptr(),
+                                                         l.config["epsilon"], 1, sums.data_ptr(), st))
+                def run(res, xin=xin, s=s, cc=cc, sums=sums, dy=dy, eps=l.config["epsilon"], relu=0 if masked else 1):
                     out = self.new(xin.h, xin.w, cc)
                     L.check(lib.miseg_bn_relu_bwd_apply(
                         xin.ptr, dy.ptr, out.ptr, xin.pixels, cc, xin.pix, dy.pix, out.pix,
                         s["scale"].data_ptr(), s["shift"].data_ptr(), s["mean"].data_ptr(),
-                        s["var"].data_ptr(), eps, 1, sums.data_ptr(), res.ptr if res is not None else None,
+                        s["var"].data_ptr(), eps, relu, sums.data_ptr(), res.ptr if res is not None else None,
                         res.pix if res is not None else 0, st))
                     return out
                 self.gview(name, "beta").copy_(sums[:cc])
@@ -1317,6 +1345,54 @@ class Trainer:
         self._join_side()
         if self.buckets is not None:
             self.buckets.flush()
+
+    def _sole_reader(self, name):
+        """The one layer that reads tensor `name`, looking through ZeroPadding2D; None if several do."""
+        cons = self.consumers.get(name, [])
+        while len(cons) == 1 and self.g.layers[cons[0]].cls == "ZeroPadding2D":
+            cons = self.consumers.get(cons[0], [])
+        return cons[0] if len(cons) == 1 else None
+
+    def _bn_mask_for(self, src_name, reader, grads):
+        """When tensor `src_name` is relu(bn(x)) -- or a Concatenate that starts with it -- and `reader` is the
+        only layer that reads it, the reader's data gradient can apply the ReLU's mask and gather the
+        BatchNormalization's two backward reductions while it stores (one pass over x and the gradient less
+        per BatchNormalization).  Returns the `bn_mask` argument of conv(), or None."""
+        if os.environ.get("MISEG_NO_FUSED_BN_BWD") or src_name in grads:
+            return None
+        g = self.g
+        relu = src_name
+        if g.layers[relu].cls == "Concatenate":
+            if self._sole_reader(relu) != reader:
+                return None
+            cat = relu
+            relu = g.layers[cat].inbound[0]
+            if self.consumers.get(relu) != [cat] or self.place.get(relu) != (cat, 0):
+                return None
+        elif self._sole_reader(relu) != reader:
+            return None
+        rl = g.layers[relu]
+        if rl.cls != "Activation" or rl.config.get("activation") != "relu":
+            return None
+        bn = g.layers[rl.inbound[0]]
+        if bn.cls != "BatchNormalization" or bn.name in self.frozen or bn.name not in self.bn_state or \
+                bn.name not in self.saved or bn.out.c % 8 or self.consumers.get(bn.name) != [relu]:
+            return None
+        s = self.bn_state[bn.name]
+        buf = s["fused"]
+        buf.zero_()
+        self.bwd_fused.add(bn.name)
+        return (self.saved[bn.name], s["scale"].data_ptr(), s["shift"].data_ptr(), bn.out.c, buf, bn.name)
+
+    def _masked_dgrad(self, layer, bn_mask, launch):
+        """launch(bn_mask) runs a data gradient; with a mask the kernel may decline (conv() returns False): the
+        layer then runs plain and its BatchNormalization makes its own reduction pass."""
+        if bn_mask is not None:
+            if launch(bn_mask) is not False:
+                self.bwd_masked[layer] = bn_mask[3]
+                return
+            self.bwd_fused.discard(bn_mask[5])
+        launch(None)
 
     def _narrow_dz(self, head):
         if head.cls != "Conv2D" or head.config["kernel_size"] != 3 or head.config["strides"] != 1 or \
@@ -1404,11 +1480,13 @@ class Trainer:
         dyv = Act(dy.t, cop, dy.c0)
         if stride == 1:
             narrow = dy.pix if dy.pix < cop else 0
+            bn_mask = self._bn_mask_for(src_name, l.name, grads) if ci % 8 == 0 else None
 
             def run(res):
                 out = self.new(xin.h, xin.w, ci)
-                self.conv(dyv, packs[0].data_ptr(), ci, k, k, 1, 1, k - 1 - pad, k - 1 - pad, out, xin.h,
-                          xin.w, residual=res, in_valid_c=narrow)
+                self._masked_dgrad(l.name, bn_mask if res is None else None, lambda bm: self.conv(
+                    dyv, packs[0].data_ptr(), ci, k, k, 1, 1, k - 1 - pad, k - 1 - pad, out, xin.h, xin.w,
+                    residual=res, in_valid_c=narrow, bn_mask=bm))
                 return out
             self._fused_dgrad(grads, src_name, l.name, dy, run)
             return
@@ -1447,13 +1525,17 @@ class Trainer:
         phased = (len(packs) > 1 and xin.c % 8 == 0 and dy.h * dy.pix * dy.w * 2 < 2 ** 31 and
                   not os.environ.get("MISEG_NO_PHASED_DGRAD"))
 
+        bn_mask = self._bn_mask_for(src_name, l.name, grads) if xin.c % 8 == 0 else None
+
         def run(res):
             out = self.new(xin.h, xin.w, xin.c)
             if phased:
-                self.conv(dyv, packs[1].data_ptr(), xin.c, 2, 2, 1, 1, 0, 0, out, xin.h, xin.w, residual=res,
-                          transposed=2)
+                launch = lambda bm: self.conv(dyv, packs[1].data_ptr(), xin.c, 2, 2, 1, 1, 0, 0, out, xin.h, xin.w,   # noqa: E731
+                                              residual=res, transposed=2, bn_mask=bm)
             else:
-                self.conv(dyv, wt.data_ptr(), xin.c, 4, 4, 2, 2, 1, 1, out, xin.h, xin.w, residual=res)
+                launch = lambda bm: self.conv(dyv, wt.data_ptr(), xin.c, 4, 4, 2, 2, 1, 1, out, xin.h, xin.w,   # noqa: E731
+                                              residual=res, bn_mask=bm)
+            self._masked_dgrad(l.name, bn_mask if res is None else None, launch)
             return out
         self._fused_dgrad(grads, src_name, l.name, dy, run)
 

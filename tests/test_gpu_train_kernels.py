@@ -480,3 +480,110 @@ def test_loss_grad_ex_focal_and_sigmoid_match_autograd(env, classes, flags, temp
     got = dz.float().cpu().numpy()
     np.testing.assert_allclose(got[..., :classes], want, rtol=2e-2, atol=2e-3 * np.abs(want).max())
     assert np.all(got[..., classes:] == 0)
+
+
+MASK_CASES = [
+    # n, h, w, cin, cout, k, stride, pad, mask_c, kernel the launcher picks
+    (2, 20, 40, 64, 128, 3, 1, 1, 128, "conv3x3_halo_pw_kernel"),     # ring kernel, every channel masked
+    (1, 17, 45, 128, 256, 3, 1, 1, 128, "conv3x3_halo_pw_kernel"),    # ragged patches; a skip tensor behind the mask
+    (2, 16, 32, 64, 64, 3, 1, 1, 64, "conv3x3_halo_ks_kernel"),       # K-split kernel
+    (2, 19, 70, 32, 32, 3, 1, 1, 32, "conv3x3_c32p_kernel"),          # persistent kernel: x loads issued by hand
+    (1, 16, 64, 32, 32, 3, 1, 1, 16, "conv3x3_c32p_kernel"),          # the second octet of a pixel unmasked
+    (2, 24, 24, 32, 64, 4, 2, 1, 64, "conv_igemm_kernel"),            # the generic tiles (a transpose-conv's gradient)
+    (1, 16, 16, 64, 64, 1, 1, 0, 64, "conv_igemm_dma_kernel"),        # 1x1 on the LDS-DMA tiles
+]
+
+
+@pytest.mark.parametrize("case", MASK_CASES)
+def test_conv_bn_relu_mask_mode(env, case):
+    """miseg_conv_desc.res_mode = MISEG_RES_BN_RELU_MASK: a data gradient that also applies the mask of the
+    ReLU behind it and gathers the BatchNormalization's two backward sums (the tf.keras FusedBatchNormGrad
+    reductions of the model.fit step, /root/reference model_train.py:284-329), against numpy on the same
+    bf16-rounded operands; miseg_bn_bwd_sums finishes the sums."""
+    L, lib, dev = env
+    n, h, w, cin, cout, k, stride, pad, mc, kernel = case
+    rng = np.random.default_rng(hash(case[:9]) % 2**32)
+    dy = bf16_round(rng.normal(0, 1, (n, h, w, cin)))
+    wt = bf16_round(rng.normal(0, 0.1, (cout, k, k, cin)))
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    x = bf16_round(rng.normal(0.3, 1.5, (n, ho, wo, mc)))           # the BatchNorm's input at the output positions
+    scale = rng.uniform(0.5, 1.5, mc).astype(np.float32) * rng.choice([-1.0, 1.0], mc).astype(np.float32)
+    shift = rng.normal(0, 0.5, mc).astype(np.float32)
+    acc = F.conv2d(torch.from_numpy(dy).permute(0, 3, 1, 2), torch.from_numpy(wt).permute(0, 3, 1, 2), stride=stride,
+                   padding=pad).permute(0, 2, 3, 1).numpy()
+    want = acc.copy()
+    want[..., :mc] *= (x * scale + shift > 0)
+    want = bf16_round(want)
+    dyd, wd, xd = dbf(dy, dev), dbf(wt, dev), dbf(x, dev)
+    out = torch.full((n, ho, wo, cout), 7.0, dtype=torch.bfloat16, device=dev)
+    sc_d, sh_d = df32(scale, dev), df32(shift, dev)
+    reps, stride_c = 32, (mc + 31) // 32 * 32
+    stats = torch.zeros((reps + 1, 2, stride_c), dtype=torch.float64, device=dev)
+    d = L.ConvDesc()
+    d.inp, d.weight, d.out = dyd.data_ptr(), wd.data_ptr(), out.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, cin, ho, wo, cout
+    d.KH = d.KW = k
+    d.stride_y = d.stride_x = stride
+    d.pad_y = d.pad_x = pad
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin, cin * w, cin * w * h
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * wo, cout * wo * ho
+    d.out_dtype, d.res_dtype, d.act, d.temperature = L.DT_BF16, L.DT_BF16, L.ACT_NONE, 1.0
+    d.residual = xd.data_ptr()
+    d.res_pix_stride, d.res_row_stride, d.res_img_stride = mc, mc * wo, mc * wo * ho
+    d.scale, d.shift = sc_d.data_ptr(), sh_d.data_ptr()
+    d.res_mode, d.res_mask_c = L.RES_BN_RELU_MASK, mc
+    d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), reps, stride_c
+    buf = C.create_string_buffer(128)
+    L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+    assert buf.value.decode().startswith(kernel), buf.value
+    L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    tol = 2.0 ** -7 * np.maximum(np.abs(want), 1e-2 * np.abs(want).max())
+    flips = np.abs(got - want) > tol
+    # a value within rounding of zero on the mask's boundary cannot flip: the mask comes from x, not from the result
+    assert flips.mean() < 1e-4, (flips.mean(), np.abs(got - want).max())
+    assert np.array_equal(got[..., :mc] == 0, (want[..., :mc] == 0) | (got[..., :mc] == 0))
+    assert np.all(got[..., :mc][(x * scale + shift) <= 0] == 0)
+    # the two sums, of the values as stored
+    s1 = got[..., :mc].astype(np.float64).sum(axis=(0, 1, 2))
+    s2 = (got[..., :mc].astype(np.float64) * x).sum(axis=(0, 1, 2))
+    tot = stats[:reps].sum(dim=0).cpu().numpy()
+    np.testing.assert_allclose(tot[0, :mc], s1, rtol=1e-5, atol=1e-4 * np.abs(s1).max())
+    np.testing.assert_allclose(tot[1, :mc], s2, rtol=1e-5, atol=1e-4 * np.abs(s2).max())
+    mean, var, eps = x.mean(axis=(0, 1, 2)).astype(np.float32), x.var(axis=(0, 1, 2)).astype(np.float32), 1e-3
+    sums = torch.empty(2 * mc, dtype=torch.float64, device=dev)
+    mean_d, var_d = df32(mean, dev), df32(var, dev)
+    L.check(lib.miseg_bn_bwd_sums(stats.data_ptr(), reps, stride_c, mc, mean_d.data_ptr(), var_d.data_ptr(), eps,
+                                  sums.data_ptr(), None))
+    torch.cuda.synchronize()
+    sm = sums.cpu().numpy()
+    np.testing.assert_allclose(sm[:mc], s1, rtol=1e-5, atol=1e-4 * np.abs(s1).max())
+    ref2 = (s2 - mean.astype(np.float64) * s1) / np.sqrt(var.astype(np.float64) + eps)
+    np.testing.assert_allclose(sm[mc:], ref2, rtol=1e-4, atol=1e-4 * np.abs(ref2).max())
+
+
+def test_conv_bn_relu_mask_mode_is_declined_where_it_is_not_built(env):
+    """fp16 storage (inference only) has no masked kernels: the call reports MISEG_E_UNSUPPORTED_SHAPE instead of
+    running without the mask."""
+    L, lib, dev = env
+    t = torch.zeros(1 << 16, dtype=torch.bfloat16, device=dev)
+    f = torch.zeros(256, dtype=torch.float32, device=dev)
+    st = torch.zeros(33 * 2 * 64, dtype=torch.float64, device=dev)
+    d = L.ConvDesc()
+    d.inp = d.weight = d.out = d.residual = t.data_ptr()
+    d.scale = d.shift = f.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = 1, 8, 8, 64, 8, 8, 64
+    d.KH = d.KW = 3
+    d.stride_y = d.stride_x = d.pad_y = d.pad_x = 1
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = 64, 512, 4096
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = 64, 512, 4096
+    d.res_pix_stride, d.res_row_stride, d.res_img_stride = 64, 512, 4096
+    d.out_dtype, d.res_dtype, d.act, d.temperature = L.DT_BF16, L.DT_BF16, L.ACT_NONE, 1.0
+    d.res_mode, d.res_mask_c = L.RES_BN_RELU_MASK, 64
+    d.stats, d.stats_replicas, d.stats_stride = st.data_ptr(), 32, 64
+    d.fmt = L.FMT_F16
+    assert lib.miseg_conv2d_fwd(C.byref(d), None) == L.E_UNSUPPORTED_SHAPE
+    d.fmt = L.FMT_BF16
+    d.res_mask_c = 12                      # not a multiple of 8
+    assert lib.miseg_conv2d_fwd(C.byref(d), None) == L.E_INVALID_ARG

@@ -161,6 +161,17 @@ def forward_errors(tr, weights):
     return out
 
 
+def _masked(tr, name, xin, grad):
+    """A data gradient whose kernel also applied the mask of the ReLU in front of the layer (the layer reads
+    relu(bn(x)), Trainer.bwd_masked): the reference gradient with that mask on its leading channels."""
+    mc = getattr(tr, "bwd_masked", {}).get(name)
+    if not mc:
+        return grad
+    grad = grad.clone()
+    grad[..., :mc] *= (xin.float().cpu()[..., :mc] > 0).float()
+    return grad
+
+
 def backward_errors(tr, weights, x_input):
     """Requires tr.keep_grads = True during backward()."""
     g = tr.g
@@ -226,7 +237,7 @@ def backward_errors(tr, weights, x_input):
                  if "bias" in weights[name] else None)
             F.conv2d(xf, wt, b, stride=l.config["strides"], padding=pad).backward(nchw(dyf))
             if dx is not None:
-                out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xf.grad))))
+                out.append((name, "dx", _rel(dx.float().cpu(), _masked(tr, name, xin, nhwc(xf.grad)))))
             out.append((name, "dw", _rel(torch.from_numpy(gw[name]["kernel"]), wt.grad.permute(2, 3, 1, 0))))
             if b is not None:
                 out.append((name, "dbias", _rel(torch.from_numpy(gw[name]["bias"]), b.grad)))
@@ -250,7 +261,7 @@ def backward_errors(tr, weights, x_input):
             xf = nchw(xin.float().cpu()).clone().requires_grad_(True)
             wt = _bf(torch.from_numpy(weights[name]["kernel"])).permute(3, 2, 0, 1).clone().requires_grad_(True)
             F.conv_transpose2d(xf, wt, stride=2, padding=1).backward(nchw(dyf))
-            out.append((name, "dx", _rel(dx.float().cpu(), nhwc(xf.grad))))
+            out.append((name, "dx", _rel(dx.float().cpu(), _masked(tr, name, xin, nhwc(xf.grad)))))
             out.append((name, "dw", _rel(torch.from_numpy(gw[name]["kernel"]), wt.grad.permute(2, 3, 1, 0))))
         elif l.cls == "BatchNormalization":
             xf = tr.saved[name].float().cpu().clone().requires_grad_(True)
