@@ -104,7 +104,7 @@ def pmc_traffic(kernel, batch, h, w, encoder, decoder):
     if k:
         return k["hbm_bytes_per_launch"]
     # a name without template arguments stands for all its instantiations: mean over their launches
-    fam = [v for n, v in kernels.items() if n.split("<")[0] == kernel]
+    fam = [v for n, v in kernels.items() if n.split("<")[0] == kernel.split("<")[0]]
     if not fam:
         return None
     return sum(v["hbm_bytes_per_launch"] * v["dispatches"] for v in fam) / sum(v["dispatches"] for v in fam)

@@ -197,7 +197,10 @@ int miseg_conv2d_fwd(const miseg_conv_desc* d, void* stream) {
 
 int miseg_conv_kernel_name(const miseg_conv_desc* d, char* buf, int32_t buflen) {
   MISEG_CHECK_ARG(d && buf && buflen > 0, "conv_kernel_name: null argument");
-  conv_kernel_name(d, buf, buflen);
+  if (d->fmt == MISEG_FMT_F16)
+    miseg_f16::conv_kernel_name(d, buf, buflen);
+  else
+    conv_kernel_name(d, buf, buflen);
   return MISEG_OK;
 }
 
@@ -714,7 +717,9 @@ int miseg_plan_op_kernel(const miseg_plan* p, int index, char* buf, int32_t bufl
                                 "upsample_nearest_kernel", "upsample_bilinear2x_kernel",
                                 "scale_shift_relu_kernel", "", "", "", "", "maxpool2x2_kernel",
                                 "im2col3x3_kernel", "head_gather_kernel", "linknet_block_kernel"};
-  if (o.kind == OP_CONV)
+  if (o.kind == OP_CONV && p->fmt == MISEG_FMT_F16)
+    miseg_f16::conv_kernel_name(&o.conv, buf, buflen);
+  else if (o.kind == OP_CONV)
     conv_kernel_name(&o.conv, buf, buflen);
   else if (o.kind == OP_CONV_HEAD)
     snprintf(buf, buflen, "conv3x3_c32_head_kernel");

@@ -569,6 +569,8 @@ __device__ __forceinline__ void direct_tile_mask(const ConvParams& p, const Dire
 // the pixel in out / out2; res: the residual's two octets (used when has_res); d2: null when
 // there is no second output; st: null, or this lane's running sum [0, 16) and sum of squares
 // [16, 32) of the stored (bf16-rounded) values of its 16 couts.
+// OUT1 = false: the launch has no first output (p.out == nullptr), only the second one.
+template <bool OUT1 = true>
 __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLane& d, const f32x16& a,
                                             bool okp, long long o_off, long long o2_off, bool has_res,
                                             const uint4 (&res)[2], const DirectOut2* d2, float* st, bool do_stats) {
@@ -613,7 +615,7 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
     }
     const uint4 pk = make_uint4(pack_h16x2_raw(o[0], o[1]), pack_h16x2_raw(o[2], o[3]), pack_h16x2_raw(o[4], o[5]),
                                 pack_h16x2_raw(o[6], o[7]));
-    *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + o_off + d.c2[q]) = pk;
+    if constexpr (OUT1) *reinterpret_cast<uint4*>(reinterpret_cast<h16_t*>(p.out) + o_off + d.c2[q]) = pk;
     if (do_stats) {
       const float r[8] = {h16lo_to_f32(pk.x), h16hi_to_f32(pk.x), h16lo_to_f32(pk.y), h16hi_to_f32(pk.y),
                           h16lo_to_f32(pk.z), h16hi_to_f32(pk.z), h16lo_to_f32(pk.w), h16hi_to_f32(pk.w)};
@@ -637,7 +639,7 @@ __device__ __forceinline__ void direct_tile(const ConvParams& p, const DirectLan
 }
 
 // All MT pixel rows of a wave (pixel index = wm * MT * 32 + b * 32 + lane % 32 through `decode`).
-template <int MT, class Decode, bool BNM = false>
+template <int MT, class Decode, bool BNM = false, bool OUT1 = true>
 __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const TileCoord& tc,
                                                      const Decode& decode, f32x16 (&acc)[MT],
                                                      int wm, int lane, const DirectLane& d,
@@ -679,7 +681,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const 
       if constexpr (BNM)
         direct_tile_mask(p, d, acc[b0 + i], okp[i], o_off[i], res[i], st, do_stats);
       else
-        direct_tile(p, d, acc[b0 + i], okp[i], o_off[i], o2_off[i], has_res, res[i], p.out2 ? &o2 : nullptr, st, do_stats);
+        direct_tile<OUT1>(p, d, acc[b0 + i], okp[i], o_off[i], o2_off[i], has_res, res[i], p.out2 ? &o2 : nullptr, st, do_stats);
     });
   });
 }
@@ -687,7 +689,7 @@ __device__ __forceinline__ void conv_epilogue_direct(const ConvParams& p, const 
 // A wave tile of NT cout groups: group a covers couts [cbase + 32 a, cbase + 32 a + 32).  BNB =
 // couts per block (for the statistics' block-level sums in `lds`, which every wave of the block
 // must reach).
-template <int MT, int NT, int BNB, class Decode, bool BNM = false>
+template <int MT, int NT, int BNB, class Decode, bool BNM = false, bool OUT1 = true>
 __device__ __forceinline__ void conv_epilogue_direct_groups(const ConvParams& p, const TileCoord& tc,
                                                             const Decode& decode, f32x16 (&acc)[NT][MT],
                                                             int wm, int cbase, int lane, unsigned char* lds) {
@@ -700,7 +702,7 @@ __device__ __forceinline__ void conv_epilogue_direct_groups(const ConvParams& p,
     if (cbase + a * 32 < p.Cout) {
       DirectLane dl;
       direct_lane_init<BNM>(p, cbase + a * 32, lane, dl);
-      conv_epilogue_direct<MT, Decode, BNM>(p, tc, decode, acc[a], wm, lane, dl, st[a], stats);
+      conv_epilogue_direct<MT, Decode, BNM, OUT1>(p, tc, decode, acc[a], wm, lane, dl, st[a], stats);
     }
   });
   if (stats) {

@@ -57,7 +57,11 @@ __device__ unsigned long long g_pw_prof[1 << 16][4];
 #define PW_TICK(i) do { } while (0)
 #endif
 
-template <int WARPS_M, int MT, bool CONVT, bool DGT = false, bool BNM = false>
+// GEN: the instantiation carries the generic (LDS-transposing) epilogue as well, for outputs the direct one does
+// not take (fp32 output or residual, ragged Cout, the head); without it the kernel fits its registers.
+// NOOUT (with GEN = false): the launch stores its second output only (out == nullptr): the unit that closes a
+// ResNet stage, whose raw sum nobody reads.
+template <int WARPS_M, int MT, bool CONVT, bool DGT = false, bool BNM = false, bool GEN = true, bool NOOUT = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParams p) {
   static_assert(!(CONVT && DGT), "one mode");
 #ifdef MISEG_PW_PROFILE
@@ -278,9 +282,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
     conv_epilogue_direct_groups<MT, 1, BN, PatchDecode<TH, TW>, true>(p, tc, dec, acc, wm, tc.cout0 + cgrp * 32, lane, lds);
     return;
   }
-  if (direct_epilogue_ok(p)) {
+  if (!GEN || direct_epilogue_ok(p)) {
     // straight from the accumulators: no LDS, no waits between the rows' stores
-    conv_epilogue_direct_groups<MT, 1, BN>(p, tc, dec, acc, wm, tc.cout0 + cgrp * 32, lane, lds);
+    conv_epilogue_direct_groups<MT, 1, BN, PatchDecode<TH, TW>, false, !NOOUT>(p, tc, dec, acc, wm, tc.cout0 + cgrp * 32, lane, lds);
 #ifdef MISEG_PW_PROFILE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // count the stores' round trip
     PW_TICK(3);
@@ -289,8 +293,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_pw_kernel(const ConvParam
 #endif
     return;
   }
-  __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
-  conv_epilogue<WARPS_N, MT, 1>(p, tc, dec, acc, lds, wm, cgrp, lane, wave);
+  if constexpr (GEN) {
+    __syncthreads();   // the epilogue regions alias the staging buffers other waves may still read
+    conv_epilogue<WARPS_N, MT, 1>(p, tc, dec, acc, lds, wm, cgrp, lane, wave);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -748,37 +754,83 @@ __global__ __launch_bounds__(256, 1) void convT_c64_kernel(const ConvParams p) {
 #endif
 }
 
+namespace {
+// Which instantiation a launch takes; the launcher and the name a profile shows both follow this.
+enum PwVariant { PW_CONVT_C64, PW_KS, PW_KS_MASK, PW_DGT, PW_DGT_MASK, PW_CONVT, PW_CONVT_DIRECT, PW_MASK, PW_DIRECT,
+                 PW_OUT2_ONLY, PW_PLAIN };
+PwVariant pw_variant(const ConvParams& p) {
+  if (p.transposed && p.Cin == 64 && p.Cout <= 32 && !p.stats) return PW_CONVT_C64;
+  // data gradients behind relu(bn(x)) (res_mask_c; validate_conv guarantees what the direct epilogue needs) run
+  // instantiations of their own (bf16 storage only), so that the others carry nothing of the mask
+  const bool mask = p.res_mask_c && !MISEG_BUILD_F16;
+  // a second output only (the convolution that closes a ResNet stage, whose raw sum nobody reads): the direct
+  // epilogue without its first store.  (The K-split kernel spills in such an instantiation and keeps the generic
+  // epilogue for its one launch of this kind.)
+  const bool out2_only = !p.out && p.out2 && p.vec_ok && (p.Cout & 7) == 0 && !p.stats &&
+                         (!p.residual || p.res_dtype == MISEG_DT_BF16) && !p.transposed && !p.dgrad_t && !p.res_mask_c;
+  if (out2_only && p.Cout > 64) return PW_OUT2_ONLY;
+  if (!p.transposed && !p.dgrad_t && p.Cout <= 64) return mask ? PW_KS_MASK : PW_KS;
+  if (p.dgrad_t) return mask ? PW_DGT_MASK : PW_DGT;
+  // The direct epilogue's conditions (direct_epilogue_ok) evaluated here: such a launch takes the instantiation
+  // without the generic epilogue, which fits its registers.  (With bf16 storage the compiler spills MORE in that
+  // instantiation, 24 registers against 8: fp16 only.)
+  const bool direct = MISEG_BUILD_F16 && p.vec_ok && p.out && p.out_dtype == MISEG_DT_BF16 && (p.Cout & 7) == 0 &&
+                      (!p.residual || p.res_dtype == MISEG_DT_BF16) && p.act != MISEG_ACT_SOFTMAX &&
+                      p.act != MISEG_ACT_SIGMOID;
+  if (p.transposed) return direct ? PW_CONVT_DIRECT : PW_CONVT;
+  if (mask) return PW_MASK;
+  return direct ? PW_DIRECT : PW_PLAIN;
+}
+}  // namespace
+
+// The kernel name of a launch as rocprofv3 prints it (without the namespace).
+void halo_pw_kernel_name(const ConvParams& p, char* buf, int len) {
+  switch (pw_variant(p)) {
+    case PW_CONVT_C64: snprintf(buf, len, "convT_c64_kernel"); break;
+    case PW_KS: snprintf(buf, len, "conv3x3_halo_ks_kernel<false>"); break;
+    case PW_KS_MASK: snprintf(buf, len, "conv3x3_halo_ks_kernel<true>"); break;
+    case PW_DGT: snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, false, true, false, true, false>"); break;
+    case PW_DGT_MASK: snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, false, true, true, true, false>"); break;
+    case PW_CONVT: snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, true, false, false, true, false>"); break;
+    case PW_CONVT_DIRECT: snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, true, false, false, false, false>"); break;
+    case PW_MASK: snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, false, false, true, true, false>"); break;
+    case PW_DIRECT: snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, false, false, false, false, false>"); break;
+    case PW_OUT2_ONLY: snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, false, false, false, false, true>"); break;
+    case PW_PLAIN: snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, false, false, false, true, false>"); break;
+  }
+}
+
 hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s) {
-  if (p.transposed && p.Cin == 64 && p.Cout <= 32 && !p.stats) {
-    // persistent, one block per CU
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int blocks = p.mtiles < cus ? p.mtiles : cus;
-    hipLaunchKernelGGL(convT_c64_kernel, dim3(blocks), dim3(256), 0, s, p);
-    return hipGetLastError();
-  }
-  // data gradients behind relu(bn(x)) (res_mask_c; validate_conv guarantees what the direct epilogue needs):
-  // instantiations of their own, so that the others carry nothing of the mask
-  if (!p.transposed && !p.dgrad_t && p.Cout <= 64) {
-    if (p.res_mask_c && !MISEG_BUILD_F16)
-      hipLaunchKernelGGL(conv3x3_halo_ks_kernel<!MISEG_BUILD_F16>, grid, dim3(256), 0, s, p);
-    else
-      hipLaunchKernelGGL(conv3x3_halo_ks_kernel<false>, grid, dim3(256), 0, s, p);
-    return hipGetLastError();
-  }
-  if (p.dgrad_t) {
-    if (p.res_mask_c && !MISEG_BUILD_F16)
+  switch (pw_variant(p)) {
+    case PW_CONVT_C64: {
+      // persistent, one block per CU
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      const int blocks = p.mtiles < cus ? p.mtiles : cus;
+      hipLaunchKernelGGL(convT_c64_kernel, dim3(blocks), dim3(256), 0, s, p);
+      break;
+    }
+    case PW_KS: hipLaunchKernelGGL(conv3x3_halo_ks_kernel<false>, grid, dim3(256), 0, s, p); break;
+    case PW_KS_MASK: hipLaunchKernelGGL(conv3x3_halo_ks_kernel<!MISEG_BUILD_F16>, grid, dim3(256), 0, s, p); break;
+    case PW_DGT: hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, true>), grid, dim3(256), 0, s, p); break;
+    case PW_DGT_MASK:
       hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, true, !MISEG_BUILD_F16>), grid, dim3(256), 0, s, p);
-    else
-      hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, true>), grid, dim3(256), 0, s, p);
-    return hipGetLastError();
+      break;
+    case PW_CONVT: hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, true>), grid, dim3(256), 0, s, p); break;
+    case PW_CONVT_DIRECT:
+      hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, true, false, false, false>), grid, dim3(256), 0, s, p);
+      break;
+    case PW_MASK:
+      hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, false, !MISEG_BUILD_F16>), grid, dim3(256), 0, s, p);
+      break;
+    case PW_DIRECT:
+      hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, false, false, false>), grid, dim3(256), 0, s, p);
+      break;
+    case PW_OUT2_ONLY:
+      hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, false, false, false, true>), grid, dim3(256), 0, s, p);
+      break;
+    case PW_PLAIN: hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false>), grid, dim3(256), 0, s, p); break;
   }
-  if (p.transposed)
-    hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, true>), grid, dim3(256), 0, s, p);
-  else if (p.res_mask_c && !MISEG_BUILD_F16)
-    hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false, false, !MISEG_BUILD_F16>), grid, dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL((conv3x3_halo_pw_kernel<1, 8, false>), grid, dim3(256), 0, s, p);
   return hipGetLastError();
 }
 

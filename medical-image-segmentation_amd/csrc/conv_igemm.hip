@@ -816,6 +816,7 @@ int validate_conv(const miseg_conv_desc* d) {
 enum KernelKind { K_REG = 0, K_REG_PRO = 1, K_DMA = 2, K_HALO = 3, K_C32 = 4, K_HALO_PW = 5 };
 
 hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s);
+void halo_pw_kernel_name(const ConvParams& p, char* buf, int len);
 bool conv_c32p_ok(const ConvParams& p);
 hipError_t launch_conv_c32p(const ConvParams& p, hipStream_t s);
 bool conv_stem7_ok(const ConvParams& p);
@@ -880,20 +881,22 @@ static void fill_params(const miseg_conv_desc* d, ConvParams& p);
 
 // Name of the kernel instantiation launch_conv() picks for `d`, as rocprofv3 prints it.
 void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
+  ConvParams pp;
+  fill_params(d, pp);
   if (d->transposed == MISEG_CONV_DGRAD_T) {
-    snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, false, true>");
+    pp.transposed = 0;
+    pp.dgrad_t = 1;
+    halo_pw_kernel_name(pp, buf, len);
     return;
   }
   const KernelChoice kc = choose_kernel(d);
-  ConvParams pp;
-  fill_params(d, pp);
   const bool persist = !(d->tile_hint & MISEG_TILE_NO_PERSIST);
   if ((d->tile_hint & 15) == 0 && persist && conv_stem7_ok(pp)) {
     snprintf(buf, len, "conv_stem7_kernel");
     return;
   }
   if (kc.kind == K_C32 && persist && conv_c32p_ok(pp)) {
-    snprintf(buf, len, "conv3x3_c32p_kernel");
+    snprintf(buf, len, "conv3x3_c32p_kernel<%s>", pp.res_mask_c && !MISEG_BUILD_F16 ? "true" : "false");
     return;
   }
   if (kc.kind == K_REG_PRO && (d->tile_hint & 15) == 0 && conv_pw_pro_ok(pp)) {
@@ -911,19 +914,16 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
                                 "", "8, 32, 4, 1, 2, 1, 1"};
   if (kc.kind == K_C32)
     snprintf(buf, len, "conv3x3_c32_kernel<8, 32>");
-  else if (kc.kind == K_HALO_PW && d->transposed && d->Cin == 64 && d->Cout <= 32 && !d->stats)
-    snprintf(buf, len, "convT_c64_kernel");
-  else if (kc.kind == K_HALO_PW && !d->transposed && d->Cout <= 64)
-    snprintf(buf, len, "conv3x3_halo_ks_kernel");
   else if (kc.kind == K_HALO_PW)
-    snprintf(buf, len, "conv3x3_halo_pw_kernel<1, 8, %s, false>", d->transposed ? "true" : "false");
+    halo_pw_kernel_name(pp, buf, len);
   else if (kc.kind == K_HALO)
     snprintf(buf, len, "conv3x3_halo_kernel<%s, %s>", halos[kc.cfg - 8], d->transposed ? "true" : "false");
   else if (kc.kind == K_DMA)
-    snprintf(buf, len, "conv_igemm_dma_kernel<%s>", shapes[kc.cfg - 1]);
+    snprintf(buf, len, "conv_igemm_dma_kernel<%s, %s>", shapes[kc.cfg - 1],
+             pp.res_mask_c && !MISEG_BUILD_F16 ? "true" : "false");
   else
-    snprintf(buf, len, "conv_igemm_kernel<%s, %s>", shapes[kc.cfg - 1],
-             kc.kind == K_REG_PRO ? "true" : "false");
+    snprintf(buf, len, "conv_igemm_kernel<%s, %s, %s>", shapes[kc.cfg - 1], kc.kind == K_REG_PRO ? "true" : "false",
+             pp.res_mask_c && !MISEG_BUILD_F16 && kc.kind != K_REG_PRO ? "true" : "false");
 }
 
 static void fill_params(const miseg_conv_desc* d, ConvParams& p) {
