@@ -83,10 +83,10 @@ def cpu_baseline(encoder, decoder, classes, h, w, weights, budget_s=30.0):
 
 PMC_FILES = {
     # (images per plan, H, W, encoder, decoder) the counter passes were collected on -> reduced file
-    (4, 1920, 2560, "resnet34", "U-Net"): "r02_d_pmc_traffic.json",
-    (8, 1920, 2560, "densenet169", "Linknet"): "r02_d_pmc_traffic_d169_linknet.json",
-    (4, 1920, 2560, "densenet169", "FPN"): "r02_d_pmc_traffic_d169_fpn.json",
-    (16, 1920, 2560, "resnet18", "U-Net-train"): "r02_d_pmc_traffic_train_r18_unet.json",
+    (4, 1920, 2560, "resnet34", "U-Net"): "r03_pmc_traffic.json",
+    (8, 1920, 2560, "densenet169", "Linknet"): "r03_pmc_traffic_d169_linknet.json",
+    (4, 1920, 2560, "densenet169", "FPN"): "r03_pmc_traffic_d169_fpn.json",
+    (16, 1920, 2560, "resnet18", "U-Net-train"): "r03_pmc_traffic_train_r18_unet.json",
 }
 
 

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Copy what scripts/profile_round.sh left under gpurun_out/r02d into profiles/ under this round's names:
+"""Copy what scripts/profile_round.sh left under gpurun_out/r03 into profiles/ under this round's names:
 the bench lines, the per-kernel duration summaries as rocprofv3 wrote them, the two counter passes of every
 configuration trimmed to this library's kernels and the columns that matter, and their reduction to HBM bytes
 per launch (scripts/pmc_traffic.py).
 
-usage: scripts/collect_profiles.py [gpurun_out/r02d] [r02_d]"""
+usage: scripts/collect_profiles.py [gpurun_out/r03] [r03]"""
 import csv
 import os
 import shutil
@@ -12,8 +12,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02d")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02_d"
+src = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r03")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 dst = os.path.join(ROOT, "profiles")
 COLS = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name",
         "Counter_Value"]
@@ -38,10 +38,16 @@ def trim(a, b):
 
 copy("bench.json", "bench.json")
 copy("ks1/ks1_kernel_stats.csv", "kernel_stats_streams1.csv")
-copy("ks1_bench.json", "kernel_stats_streams1_bench.json")
+copy("ks1_bench.txt", "kernel_stats_streams1_bench.json")
 copy("ks2/ks2_kernel_stats.csv", "kernel_stats_streams2.csv")
+copy("ks2_bench.txt", "kernel_stats_streams2_bench.json")
+for name in ("d169_linknet", "d169_fpn"):
+    copy("ks_%s/ks_%s_kernel_stats.csv" % (name, name), "kernel_stats_%s.csv" % name)
+    copy("ks_%s_bench.txt" % name, "kernel_stats_%s_bench.json" % name)
 copy("kst/kst_kernel_stats.csv", "train_kernel_stats_batch16.csv")
 copy("kst_bench.txt", "train_kernel_stats_batch16_bench.txt")
+copy("kst_d169_fpn/kst_d169_fpn_kernel_stats.csv", "train_kernel_stats_d169_fpn_batch4.csv")
+copy("kst_d169_fpn_bench.txt", "train_kernel_stats_d169_fpn_batch4_bench.txt")
 for cfg, suffix in (("r34_unet", ""), ("d169_linknet", "_d169_linknet"), ("d169_fpn", "_d169_fpn"),
                     ("train_r18_unet", "_train_r18_unet")):
     f = trim("fetch_%s/fetch_counter_collection.csv" % cfg, "pmc_fetch_size%s.csv" % suffix)
