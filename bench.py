@@ -90,6 +90,18 @@ PMC_FILES = {
 }
 
 
+def all_reduce_scalar(dist, t, op=None):
+    """In-place all-reduce of a small device tensor: RCCL takes it as it is, gloo (rehearsals) gets a host copy."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(t, op=op)
+    else:
+        host = t.cpu()
+        dist.all_reduce(host, op=op)
+        t.copy_(host)
+    return t
+
+
 def pmc_traffic(kernel, batch, h, w, encoder, decoder):
     """HBM bytes per launch of `kernel` from the committed counter passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE over the same command and configuration, reduced by scripts/pmc_traffic.py); None for a
@@ -160,7 +172,7 @@ def training_leg(args, dev, rank, world, dist, h, w, augment=False, global_batch
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_scalar(dist, t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
     peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     # every rank runs the profiled step: it all-reduces its gradient buckets like any other step
@@ -377,13 +389,22 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # MISEG_BENCH_REHEARSAL=1: the ranks share the GPUs that are there (rank % device count) and talk over gloo --
+    # RCCL refuses two ranks on one device.  For walking the N > 1 code path on a one-GPU box; its numbers mean
+    # nothing and the line says so.
+    rehearsal = bool(os.environ.get("MISEG_BENCH_REHEARSAL")) and world > 1
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import miseg_amd
     from miseg_amd import engine, netspec
@@ -426,7 +447,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_scalar(dist, t, dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     train = None
@@ -436,7 +457,7 @@ def main():
     if dist is not None:
         # what RCCL itself saw: the sum of one 1 per rank
         t = torch.ones(1, dtype=torch.float32, device=dev)
-        dist.all_reduce(t)
+        all_reduce_scalar(dist, t)
         ranks_seen = int(t.item())
     if not args.no_train:
         train = training_leg(args, dev, rank, world, dist, h, w)
@@ -533,6 +554,8 @@ def main():
         if dist is not None:
             result["world"] = {"world_size": dist.get_world_size(), "ranks_in_rccl_allreduce": ranks_seen,
                                "backend": dist.get_backend()}
+            if rehearsal:
+                result["world"]["rehearsal"] = "ranks share GPUs over gloo: the N > 1 code path only, not a measurement"
         result["roofline"]["whole_pass"] = whole_pass(args.encoder, args.decoder, h, w, images / elapsed / world,
                                                       conv_flops / args.batch / 1e9, sum(eng.op_bytes) / args.batch / 1e9,
                                                       nops)

@@ -102,3 +102,27 @@ def test_train_predict_evaluate_cli(pkg, tmp_path):
     with open(os.path.join(run_dir, "train_config_%s.json" % runs[0])) as f:
         cfg2 = json.load(f)
     assert len(cfg2["train_metrics"]["loss"]) == 3
+
+
+def test_bench_two_rank_path(pkg, tmp_path):
+    """bench.py under torch.distributed.run with two ranks: the line the driver's N > 1 runs print.  On the test
+    box's one GPU the ranks share the device and talk over gloo (MISEG_BENCH_REHEARSAL: RCCL refuses two ranks on
+    one device), small images: what is checked is the N > 1 code path -- sharded inference, the weak and the
+    strong training leg with their bucketed all-reduce, the rank count the collective itself saw."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MISEG_BENCH_REHEARSAL="1")
+    args = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+            "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--height", "256",
+            "--width", "320", "--batch", "2", "--steps", "2", "--warmup", "1", "--train-batch", "4",
+            "--train-global-batch", "4", "--train-steps", "1", "--train-warmup", "1", "--no-extra",
+            "--no-cpu-baseline"]
+    r = subprocess.run(args, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                       text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["world"]["world_size"] == 2 and d["world"]["ranks_in_rccl_allreduce"] == 2
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["train"]["scaling"] == "weak" and d["train"]["global_batch"] == 8 and d["train"]["value"] > 0
+    assert d["train_strong"]["scaling"] == "strong" and d["train_strong"]["global_batch"] == 4
+    assert "2 images per GPU" in d["train_strong"]["config"]["workload"] or "batch 2 per GPU" in d["train_strong"]["config"]["workload"]
