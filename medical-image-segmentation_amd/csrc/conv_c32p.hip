@@ -18,6 +18,11 @@
 //    right after the next patch's halo, by hand, and awaited by the wait that halo needs anyway: a
 //    load the compiler sees would put a full vmcnt(0) in front of the arithmetic, i.e. behind the
 //    halo prefetch.
+//  * With a prologue (ConvParams::in_scale: the input is relu(in * in_scale + in_shift), the BatchNorm + ReLU
+//    apply pass of the training forward that then never runs as a pass of its own) the halo is transformed
+//    where it lies: thread t owns 16-byte slot t % 4 of pixels t / 4 + 64 k, so its 16 coefficients stay in
+//    registers; pixels outside the image stay zero (they are the convolution's padding, not bn(0)); one
+//    more barrier per patch.  LDS accesses by hand, as everywhere behind a pending LDS-DMA.
 #include "conv_common.h"
 
 namespace MISEG_KNS {
@@ -43,7 +48,7 @@ __device__ unsigned long long g_cp_prof[4096][8];
 #define CP_TICK(i) do { } while (0)
 #endif
 
-template <bool BNM>
+template <bool BNM, bool PRO = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p) {
 #ifdef MISEG_CP_PROFILE
   unsigned long long cp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cp_last = wall_clock64();
@@ -103,6 +108,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
     const int hx = hr - hy * HWD;
     hl[j] = hr < CP_HROWS && sl < 4 ? (hy | (hx << 8) | (sl << 16)) : -1;
   }
+  // ---- prologue: this thread's slot of pixels tid / 4 + 64 k; pixels past the halo are parked on the padding slot
+  //      of their pixel modulo the halo (nobody reads it) ----
+  constexpr int NPRO = (CP_HROWS + 63) / 64;
+  float psc[8], psh[8];
+  int pro_h[NPRO];
+  unsigned pro_a[NPRO];
+  if constexpr (PRO) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      psc[j] = p.in_scale[(tid & 3) * 8 + j];
+      psh[j] = p.in_shift[(tid & 3) * 8 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < NPRO; ++k) {
+      const int px = (tid >> 2) + 64 * k;
+      const bool in_halo = px < CP_HROWS;
+      const int hy = px / HWD, hx = px - hy * HWD;
+      pro_h[k] = in_halo ? (hy | (hx << 8)) : -1;
+      pro_a[k] = lds_a + (in_halo ? px * PITCH + (tid & 3) * 16 : (px - CP_HROWS) * PITCH + 64);
+    }
+  }
   // Patch order: blocks b, b + 8, .. share an XCD and its L2; each XCD walks its own contiguous
   // eighth of the patches, its blocks side by side.
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -153,6 +179,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
     const unsigned xl = xl0 + cur * CP_HALO_BYTES;
     int n, y0, x0;
     patch_origin(tile, n, y0, x0);
+    if constexpr (PRO) {
+      h16x8 v[NPRO];
+      static_for<NPRO>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        ds_read_b128_at<0>(v[k], pro_a[k] + cur * CP_HALO_BYTES);
+      });
+      static_for<NPRO>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        lgkm_wait<NPRO - 1 - k>(v[k]);
+        const int hy = pro_h[k] & 255, hx = (pro_h[k] >> 8) & 255;
+        const bool ok = pro_h[k] >= 0 && (unsigned)(y0 - 1 + hy) < (unsigned)p.H && (unsigned)(x0 - 1 + hx) < (unsigned)p.W;
+        const u32x4 in = __builtin_bit_cast(u32x4, v[k]);
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = fmaxf(h16lo_to_f32(in[j]) * psc[2 * j] + psh[2 * j], 0.f);
+          const float hi = fmaxf(h16hi_to_f32(in[j]) * psc[2 * j + 1] + psh[2 * j + 1], 0.f);
+          o[j] = ok ? pack_h16x2_raw(lo, hi) : 0u;
+        }
+        const unsigned dst = pro_a[k] + cur * CP_HALO_BYTES;
+        asm volatile("ds_write_b128 %0, %1" ::"v"(dst), "v"(o) : "memory");
+      });
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     const int ox = x0 + lrow;
     // x of relu(bn(x)) at this lane's two output pixels, two octets each (lanes without a pixel or an
     // octet read the zero line, so that every lane's loads count alike)
@@ -313,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32p_kernel(const ConvParams p
 // stored as 16 bytes, or the softmax / sigmoid head (fp32 out, Cout <= 4); no residual, no second output.
 bool conv_c32p_ok(const ConvParams& p) {
   if ((p.residual && !p.res_mask_c) || p.out2 || !p.out) return false;
+  if (p.in_scale && (MISEG_BUILD_F16 || p.res_mask_c || p.in_valid_c < 32)) return false;
   if (p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID)
     return p.out_dtype == MISEG_DT_F32 && p.Cout <= 4 && !p.stats;
   return p.vec_ok && p.out_dtype == MISEG_DT_BF16 && (p.Cout & 7) == 0;
@@ -322,7 +373,9 @@ hipError_t launch_conv_c32p(const ConvParams& p, hipStream_t s) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const int blocks = p.mtiles < 2 * cus ? p.mtiles : 2 * cus;
-  if (p.res_mask_c && !MISEG_BUILD_F16)
+  if (p.in_scale)      // (conv_c32p_ok admits a prologue only where this instantiation exists)
+    hipLaunchKernelGGL((conv3x3_c32p_kernel<false, !MISEG_BUILD_F16>), dim3(blocks), dim3(256), 0, s, p);
+  else if (p.res_mask_c && !MISEG_BUILD_F16)
     hipLaunchKernelGGL(conv3x3_c32p_kernel<!MISEG_BUILD_F16>, dim3(blocks), dim3(256), 0, s, p);
   else
     hipLaunchKernelGGL(conv3x3_c32p_kernel<false>, dim3(blocks), dim3(256), 0, s, p);

@@ -835,7 +835,7 @@ struct KernelChoice {
   int cfg;  // 1..7 index into kCfgs; 8..10 halo variants
 };
 
-static KernelChoice choose_kernel(const miseg_conv_desc* d) {
+static KernelChoice choose_kernel_base(const miseg_conv_desc* d) {
   const int hint = d->tile_hint & 15;
   const bool pro = d->in_scale != nullptr;
   const bool halo_ok = !pro && !d->transposed && d->KH == 3 && d->KW == 3 && d->stride_y == 1 &&
@@ -877,6 +877,19 @@ static KernelChoice choose_kernel(const miseg_conv_desc* d) {
   return {K_REG, cfg};
 }
 
+// A prologue (in_scale: the input is relu(in * in_scale + in_shift)) lives in the register-staged generic kernel
+// and, for the 32-channel 3x3 layers it can take, in the persistent 32-channel kernel (conv_c32p_ok decides, on
+// the filled-in parameters): there the layer is chosen as if it had no prologue.
+static KernelChoice choose_kernel(const miseg_conv_desc* d, const ConvParams& p) {
+  if (d->in_scale && !(d->tile_hint & MISEG_TILE_NO_PERSIST)) {
+    miseg_conv_desc e = *d;
+    e.in_scale = e.in_shift = nullptr;
+    const KernelChoice k = choose_kernel_base(&e);
+    if (k.kind == K_C32 && conv_c32p_ok(p)) return k;
+  }
+  return choose_kernel_base(d);
+}
+
 static void fill_params(const miseg_conv_desc* d, ConvParams& p);
 
 // Name of the kernel instantiation launch_conv() picks for `d`, as rocprofv3 prints it.
@@ -889,14 +902,17 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
     halo_pw_kernel_name(pp, buf, len);
     return;
   }
-  const KernelChoice kc = choose_kernel(d);
+  const KernelChoice kc = choose_kernel(d, pp);
   const bool persist = !(d->tile_hint & MISEG_TILE_NO_PERSIST);
   if ((d->tile_hint & 15) == 0 && persist && conv_stem7_ok(pp)) {
     snprintf(buf, len, "conv_stem7_kernel");
     return;
   }
   if (kc.kind == K_C32 && persist && conv_c32p_ok(pp)) {
-    snprintf(buf, len, "conv3x3_c32p_kernel<%s>", pp.res_mask_c && !MISEG_BUILD_F16 ? "true" : "false");
+    if (pp.in_scale)
+      snprintf(buf, len, "conv3x3_c32p_kernel<false, true>");
+    else
+      snprintf(buf, len, "conv3x3_c32p_kernel<%s, false>", pp.res_mask_c && !MISEG_BUILD_F16 ? "true" : "false");
     return;
   }
   if (kc.kind == K_REG_PRO && (d->tile_hint & 15) == 0 && conv_pw_pro_ok(pp)) {
@@ -991,7 +1007,7 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   if (rc != MISEG_OK) return rc;
   ConvParams p;
   fill_params(d, p);
-  if (d->in_valid_c > 0 && (d->transposed || choose_kernel(d).kind != K_C32 || !conv_c32p_ok(p) ||
+  if (d->in_valid_c > 0 && (d->transposed || choose_kernel(d, p).kind != K_C32 || !conv_c32p_ok(p) ||
                             (d->tile_hint & MISEG_TILE_NO_PERSIST))) {
     set_error("conv: in_valid_c needs a 3x3 stride-1 layer with Cin = 32, Cout <= 32, 16-bit output, no residual");
     return MISEG_E_UNSUPPORTED_SHAPE;
@@ -1015,7 +1031,7 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     }
     return MISEG_OK;
   }
-  const KernelChoice kc = choose_kernel(d);
+  const KernelChoice kc = choose_kernel(d, p);
   const int cfg = kc.cfg;
   const bool pro = kc.kind == K_REG_PRO;
   const bool dma = kc.kind == K_DMA;

@@ -587,3 +587,71 @@ def test_conv_bn_relu_mask_mode_is_declined_where_it_is_not_built(env):
     d.fmt = L.FMT_BF16
     d.res_mask_c = 12                      # not a multiple of 8
     assert lib.miseg_conv2d_fwd(C.byref(d), None) == L.E_INVALID_ARG
+
+
+@pytest.mark.parametrize("case", [(2, 19, 70, 32, 0), (1, 8, 32, 32, 0), (1, 37, 45, 16, 0), (2, 16, 64, 3, 1),
+                                  (1, 21, 33, 3, 1)])
+def test_conv_c32p_prologue(env, case):
+    """miseg_conv_desc.in_scale / in_shift on a 32-channel 3x3 layer: the persistent kernel applies
+    relu(x * scale + shift) -- the BatchNormalization + ReLU pair in front of the convolution
+    (/root/reference utils/model.py:176-186 builds Conv-BN-ReLU chains) -- to the halo tile in LDS, so that
+    the activated tensor is never written.  Against the two steps done one after the other on the same
+    bf16-rounded operands; the zero padding stays zero (it is not bn(0)); with statistics of the stored output and
+    as the softmax head."""
+    L, lib, dev = env
+    n, h, w, cout, head = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = bf16_round(rng.normal(0.2, 1.0, (n, h, w, 32)))
+    wt = bf16_round(rng.normal(0, 0.1, (cout, 3, 3, 32)))
+    scale = rng.uniform(0.5, 1.5, 32).astype(np.float32) * rng.choice([-1.0, 1.0], 32).astype(np.float32)
+    shift = rng.normal(0.3, 0.5, 32).astype(np.float32)              # bn(0) != 0: the padding must not see it
+    a = bf16_round(np.maximum(x * scale + shift, 0))
+    acc = F.conv2d(torch.from_numpy(a).permute(0, 3, 1, 2), torch.from_numpy(wt).permute(0, 3, 1, 2),
+                   padding=1).permute(0, 2, 3, 1).numpy()
+    xd, wd = dbf(x, dev), dbf(wt, dev)
+    sc_d, sh_d = df32(scale, dev), df32(shift, dev)
+    d = L.ConvDesc()
+    d.inp, d.weight = xd.data_ptr(), wd.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, 32, h, w, cout
+    d.KH = d.KW = 3
+    d.stride_y = d.stride_x = d.pad_y = d.pad_x = 1
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = 32, 32 * w, 32 * w * h
+    d.in_scale, d.in_shift = sc_d.data_ptr(), sh_d.data_ptr()
+    d.temperature = 1.0
+    if head:
+        bias = rng.normal(0, 0.3, cout).astype(np.float32)
+        bias_d = df32(bias, dev)
+        out = torch.full((n, h, w, cout), 7.0, dtype=torch.float32, device=dev)
+        d.out, d.out_dtype, d.act, d.shift = out.data_ptr(), L.DT_F32, L.ACT_SOFTMAX, bias_d.data_ptr()
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * w, cout * w * h
+        z = acc + bias
+        e = np.exp(z - z.max(axis=-1, keepdims=True))
+        want = e / e.sum(axis=-1, keepdims=True)
+    else:
+        out = torch.full((n, h, w, cout), 7.0, dtype=torch.bfloat16, device=dev)
+        reps, stride_c = 32, 32
+        stats = torch.zeros((reps + 1, 2, stride_c), dtype=torch.float64, device=dev)
+        d.out, d.out_dtype, d.act = out.data_ptr(), L.DT_BF16, L.ACT_NONE
+        d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * w, cout * w * h
+        d.stats, d.stats_replicas, d.stats_stride = stats.data_ptr(), reps, stride_c
+        want = bf16_round(acc)
+    buf = C.create_string_buffer(128)
+    L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+    assert buf.value.decode() == "conv3x3_c32p_kernel<false, true>", buf.value
+    L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
+    torch.cuda.synchronize()
+    got = out.float().cpu().numpy()
+    if head:
+        assert np.abs(got - want).max() < 2e-3
+    else:
+        tol = 2.0 ** -7 * np.maximum(np.abs(want), 1e-2 * np.abs(want).max())
+        assert (np.abs(got - want) > tol).mean() < 1e-4, np.abs(got - want).max()
+        tot = stats[:reps].sum(dim=0).cpu().numpy()
+        s1 = got.astype(np.float64).sum(axis=(0, 1, 2))
+        s2 = (got.astype(np.float64) ** 2).sum(axis=(0, 1, 2))
+        np.testing.assert_allclose(tot[0, :cout], s1, rtol=1e-5, atol=1e-4 * np.abs(s1).max())
+        np.testing.assert_allclose(tot[1, :cout], s2, rtol=1e-5, atol=1e-4 * np.abs(s2).max())
+    # fp16 storage has no such instantiation: the layer goes to the generic prologue kernel there
+    d.fmt = L.FMT_F16
+    L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+    assert "c32p" not in buf.value.decode(), buf.value
