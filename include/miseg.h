@@ -467,6 +467,12 @@ typedef struct miseg_wgrad_desc {
   int64_t dy_img;
   int32_t tile_hint;   /* 0 = automatic; 1 = per-tap split-K kernel; 2 = halo-resident kernel
                           (stride 1, square filter up to 3x3, Cin % 32 == 0) */
+  /* X prologue: when set, the layer's input is relu(x * x_scale[ci] + x_shift[ci]) -- the BatchNormalization +
+     ReLU in front of the layer whose forward pass ran with miseg_conv_desc.in_scale / in_shift, so that the
+     activated tensor was never stored.  Both or neither, 16-byte aligned fp32 [Cin]; built for 3x3 stride-1
+     layers with Cin, Cout <= 32 (MISEG_E_UNSUPPORTED_SHAPE elsewhere: store the activated tensor then). */
+  const float* x_scale;
+  const float* x_shift;
 } miseg_wgrad_desc;
 int miseg_conv2d_wgrad(const miseg_wgrad_desc* d, void* stream);
 

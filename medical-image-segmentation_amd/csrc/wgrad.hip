@@ -39,6 +39,8 @@ struct WgradParams {
   long long dy_img;
   int M, ksteps_total, ksplit, ksteps_per_split;
   int co_tiles, ci_tiles, taps;
+  const float* x_scale;     // X operand = relu(x * x_scale[ci] + x_shift[ci]) when set (halo kernel, 3x3, 32 x 32)
+  const float* x_shift;
 };
 
 template <int BC>
@@ -370,6 +372,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_alltaps_kernel(const WgradParams
 //
 // Waves: 4.  CO_T x CI_T (32 or 64 each) is cut into 32x32 sub-tiles; when there are fewer than 4,
 // the remaining factor splits the pixels (the two 16-pixel column windows, then row halves).
+//
+// XPRO: the layer's input is relu(x * x_scale + x_shift) of a tensor that was never stored activated (the
+// forward convolution applied the BatchNorm + ReLU to its halo tile, conv_c32p.hip); the same happens here to
+// the X halo tile once it has landed, every lane on the 16-byte pieces it requested, pixels outside the image
+// left at zero (they are padding, not bn(0)).
 template <int N, typename F>
 __device__ __forceinline__ void wg_static_for(F&& f) {
   if constexpr (N > 0) {
@@ -378,7 +385,7 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
   }
 }
 
-template <int KH, int KW, int CO_T, int CI_T>
+template <int KH, int KW, int CO_T, int CI_T, bool XPRO = false>
 __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradParams p) {
   constexpr int TH = 8, TW = 32;
   constexpr int HR = TH + KH - 1, HWD = TW + KW - 1, HP = HR * HWD;
@@ -500,6 +507,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_halo_kernel(const WgradParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if constexpr (XPRO) {
+#pragma unroll
+      for (int j = 0; j < (XNI + 3) / 4; ++j) {
+        const int inst = j * 4 + wave;
+        if (inst < XNI) {
+          const int hp = inst * XPPI + lane / XLPR, slot = lane % XLPR;
+          const int hr = hp / HWD, hc = hp - hr * HWD;
+          const int iy = oy0 + hr - p.pad_y, ix = ox0 + hc - p.pad_x;
+          const int c = ci0 + xswz(hp, slot) * 8;
+          const bool ok = hp < HP && c < p.Cin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          if (ok) {
+            uint4* piece = reinterpret_cast<uint4*>(xt + inst * 1024 + lane * 16);
+            const uint4 v = *piece;
+            const float4 s0 = *reinterpret_cast<const float4*>(p.x_scale + c), s1 = *reinterpret_cast<const float4*>(p.x_scale + c + 4);
+            const float4 t0 = *reinterpret_cast<const float4*>(p.x_shift + c), t1 = *reinterpret_cast<const float4*>(p.x_shift + c + 4);
+            uint4 o;
+            o.x = pack_bf16x2(fmaxf(bf16lo_to_f32(v.x) * s0.x + t0.x, 0.f), fmaxf(bf16hi_to_f32(v.x) * s0.y + t0.y, 0.f));
+            o.y = pack_bf16x2(fmaxf(bf16lo_to_f32(v.y) * s0.z + t0.z, 0.f), fmaxf(bf16hi_to_f32(v.y) * s0.w + t0.w, 0.f));
+            o.z = pack_bf16x2(fmaxf(bf16lo_to_f32(v.z) * s1.x + t1.x, 0.f), fmaxf(bf16hi_to_f32(v.z) * s1.y + t1.y, 0.f));
+            o.w = pack_bf16x2(fmaxf(bf16lo_to_f32(v.w) * s1.z + t1.z, 0.f), fmaxf(bf16hi_to_f32(v.w) * s1.w + t1.w, 0.f));
+            *piece = o;
+          }
+        }
+      }
+      __syncthreads();
+    }
 
     // w_c: the column window when it is a compile-time choice (WK == 1), else 0 (folded into the bases)
     auto roll = [&](auto rows_c, auto w_c) __attribute__((always_inline)) {
@@ -578,6 +611,8 @@ static void launch_halo_wgrad(const WgradParams& p, hipStream_t stream) {
     hipLaunchKernelGGL((wgrad_halo_kernel<KH, KW, 64, 32>), grid, dim3(256), 0, stream, q);
   else if (ci64)
     hipLaunchKernelGGL((wgrad_halo_kernel<KH, KW, 32, 64>), grid, dim3(256), 0, stream, q);
+  else if (q.x_scale && KH == 3)      // (launch_wgrad admits a prologue only for this shape)
+    hipLaunchKernelGGL((wgrad_halo_kernel<KH, KW, 32, 32, KH == 3>), grid, dim3(256), 0, stream, q);
   else
     hipLaunchKernelGGL((wgrad_halo_kernel<KH, KW, 32, 32>), grid, dim3(256), 0, stream, q);
 }
@@ -611,6 +646,8 @@ int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream) {
   p.taps = d->KH * d->KW;
   p.co_tiles = p.ci_tiles = 1;
   p.ksplit = p.ksteps_per_split = 1;
+  p.x_scale = d->x_scale;
+  p.x_shift = d->x_shift;
   const bool halo_shape = d->stride_y == 1 && d->stride_x == 1 && d->KH == d->KW && d->KH <= 3 &&
                           d->pad_y >= 0 && d->pad_x >= 0 && d->pad_y < d->KH && d->pad_x < d->KW &&
                           (d->Cin & 31) == 0;
@@ -619,6 +656,14 @@ int launch_wgrad(const miseg_wgrad_desc* d, hipStream_t stream) {
   if (d->tile_hint == 2 && !halo_shape) {
     set_error("wgrad: the halo kernel needs stride 1, a square filter up to 3x3 and Cin %% 32 == 0");
     return MISEG_E_UNSUPPORTED_SHAPE;
+  }
+  if (d->x_scale || d->x_shift) {
+    MISEG_CHECK_ARG(d->x_scale && d->x_shift && ((uintptr_t)d->x_scale & 15) == 0 && ((uintptr_t)d->x_shift & 15) == 0,
+                    "wgrad: the X prologue needs both x_scale and x_shift, 16-byte aligned");
+    if (!(halo_shape && want_halo && d->KH == 3 && d->Cin <= 32 && d->Cout <= 32)) {
+      set_error("wgrad: the X prologue is built for the halo kernel on 3x3 layers with Cin, Cout <= 32");
+      return MISEG_E_UNSUPPORTED_SHAPE;
+    }
   }
   if (halo_shape && want_halo) {
     if (d->KH == 3) launch_halo_wgrad<3, 3>(p, stream);

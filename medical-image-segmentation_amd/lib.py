@@ -102,6 +102,7 @@ class WgradDesc(C.Structure):
         ("x_pix", C.c_int32), ("x_row", C.c_int32), ("x_img", C.c_int64),
         ("dy_pix", C.c_int32), ("dy_row", C.c_int32), ("dy_img", C.c_int64),
         ("tile_hint", C.c_int32),
+        ("x_scale", C.c_void_p), ("x_shift", C.c_void_p),
     ]
 
 

@@ -655,3 +655,40 @@ def test_conv_c32p_prologue(env, case):
     d.fmt = L.FMT_F16
     L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
     assert "c32p" not in buf.value.decode(), buf.value
+
+
+@pytest.mark.parametrize("case", [(2, 17, 45, 32), (1, 8, 32, 8), (1, 40, 70, 16)])
+def test_wgrad_x_prologue(env, case):
+    """miseg_wgrad_desc.x_scale / x_shift: the weight gradient of a 3x3 layer whose input relu(bn(x)) was never
+    stored (its forward pass ran with miseg_conv_desc.in_scale): the halo kernel activates the X tile in LDS.
+    Against autograd on the activated, bf16-rounded tensor; pixels outside the image are padding, not bn(0).
+    Shapes the prologue is not built for are declined."""
+    L, lib, dev = env
+    n, h, w, cout = case
+    rng = np.random.default_rng(hash(case) % 2**32)
+    x = bf16_round(rng.normal(0.2, 1.0, (n, h, w, 32)))
+    scale = rng.uniform(0.5, 1.5, 32).astype(np.float32) * rng.choice([-1.0, 1.0], 32).astype(np.float32)
+    shift = rng.normal(0.3, 0.5, 32).astype(np.float32)
+    a = bf16_round(np.maximum(x * scale + shift, 0))
+    dy = bf16_round(rng.normal(0, 1, (n, h, w, cout)))
+    wt = torch.zeros((cout, 32, 3, 3), requires_grad=True)
+    F.conv2d(torch.from_numpy(a).permute(0, 3, 1, 2), wt, padding=1).backward(torch.from_numpy(dy).permute(0, 3, 1, 2))
+    want = wt.grad.permute(0, 2, 3, 1).numpy()
+    xd, dyd = dbf(x, dev), dbf(dy, dev)
+    sc_d, sh_d = df32(scale, dev), df32(shift, dev)
+    dw = torch.zeros((cout, 3, 3, 32), dtype=torch.float32, device=dev)
+    d = L.WgradDesc()
+    d.x, d.dy, d.dw = xd.data_ptr(), dyd.data_ptr(), dw.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, 32, h, w, cout
+    d.KH = d.KW = 3
+    d.stride_y = d.stride_x = d.pad_y = d.pad_x = 1
+    d.x_pix, d.x_row, d.x_img = 32, 32 * w, 32 * w * h
+    d.dy_pix, d.dy_row, d.dy_img = cout, cout * w, cout * w * h
+    d.x_scale, d.x_shift = sc_d.data_ptr(), sh_d.data_ptr()
+    L.check(lib.miseg_conv2d_wgrad(C.byref(d), None))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dw.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+    d.tile_hint = 1                                        # the per-tap kernel has no prologue
+    assert lib.miseg_conv2d_wgrad(C.byref(d), None) == L.E_UNSUPPORTED_SHAPE
+    d.tile_hint, d.x_shift = 0, None
+    assert lib.miseg_conv2d_wgrad(C.byref(d), None) == L.E_INVALID_ARG
