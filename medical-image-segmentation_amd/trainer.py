@@ -34,10 +34,13 @@ def _c32(c):
 
 
 class Act:
-    """bf16 NHWC activation (or gradient) view: channels [c0, c0 + c) of `t`."""
+    """bf16 NHWC activation (or gradient) view: channels [c0, c0 + c) of `t`.
+    pro = (scale, shift): the activation is relu(t * scale + shift) of the stored tensor -- a BatchNormalization +
+    ReLU whose apply pass did not run because the one layer that reads the result applies it on the way in
+    (miseg_conv_desc.in_scale, miseg_wgrad_desc.x_scale)."""
 
-    def __init__(self, t, c, c0=0):
-        self.t, self.c, self.c0 = t, c, c0
+    def __init__(self, t, c, c0=0, pro=None):
+        self.t, self.c, self.c0, self.pro = t, c, c0, pro
 
     @property
     def n(self):
@@ -64,10 +67,14 @@ class Act:
         return self.n * self.h * self.w
 
     def slice(self, c0, c):
+        assert self.pro is None, "a tensor with a pending BatchNorm + ReLU has one reader, which takes all of it"
         return Act(self.t, c, self.c0 + c0)
 
     def float(self):
-        return self.t[..., self.c0:self.c0 + self.c].float()
+        v = self.t[..., self.c0:self.c0 + self.c].float()
+        if self.pro is not None:
+            v = torch.relu(v * self.pro[0][:self.c] + self.pro[1][:self.c]).to(torch.bfloat16).float()
+        return v
 
 
 class Seg:
@@ -632,6 +639,8 @@ class Trainer:
         d.Ho, d.Wo, d.Cout = ho, wo, cout
         d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
         d.in_pix_stride, d.in_row_stride, d.in_img_stride = x.pix, x.pix * x.w, x.pix * x.w * x.h
+        if x.pro is not None:
+            d.in_scale, d.in_shift = x.pro[0].data_ptr(), x.pro[1].data_ptr()
         if transposed == 2:                       # data gradient of a transpose conv: x is dY (2ho x 2wo)
             assert (x.h, x.w) == (2 * ho, 2 * wo)
             d.H, d.W = ho, wo
@@ -785,22 +794,63 @@ class Trainer:
         d.Cin, d.Ho, d.Wo, d.Cout = cin, ho, wo, cout
         d.KH, d.KW, d.stride_y, d.stride_x, d.pad_y, d.pad_x = kh, kw, sy, sx, py, px
         d.dy_pix, d.dy_row, d.dy_img = dy_strides
+        if getattr(x, "pro", None) is not None:
+            d.x_scale, d.x_shift = x.pro[0].data_ptr(), x.pro[1].data_ptr()
         halo = sx == 1 and sy == 1 and kh == kw and kh <= 3 and cin % 32 == 0 and 0 <= py < kh and 0 <= px < kw
         thin = not halo and cin <= 32 and cout <= 64 and 2 <= kh * kw <= 8
         self.lib.note("wgrad_halo_kernel" if halo else ("wgrad_alltaps_kernel" if thin else "conv_wgrad_kernel"),
                       d.N * ho * wo * cout * kh * kw * cin,
                       d.N * d.H * d.W * cin * 2 + d.N * ho * wo * cout * 2 + cout * kh * kw * cin * 4)
         if self.side is None or not side:
-            L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.stream()))
+            rc = self.lib.miseg_conv2d_wgrad(C.byref(d), self.stream())
+        else:
+            main = torch.cuda.current_stream(self.dev)
+            ev = torch.cuda.Event()
+            ev.record(main)                       # dy (and everything before it) is ready
+            self.side.wait_event(ev)
+            rc = self.lib.miseg_conv2d_wgrad(C.byref(d), self.side.cuda_stream)
+        if rc == L.E_UNSUPPORTED_SHAPE and d.x_scale:
+            # no kernel with the prologue for this shape: the activated tensor is stored after all
+            return self.wgrad(self._stored(x), dy_ptr, dy_strides, dw_ptr, cin, cout, kh, kw, sy, sx, py, px, ho, wo,
+                              x_geom=x_geom, dy_t=dy_t, side=side)
+        L.check(rc)
+        if self.side is None or not side:
             return
-        main = torch.cuda.current_stream(self.dev)
-        ev = torch.cuda.Event()
-        ev.record(main)                       # dy (and everything before it) is ready
-        self.side.wait_event(ev)
-        L.check(self.lib.miseg_conv2d_wgrad(C.byref(d), self.side.cuda_stream))
         for t in (dy_t, getattr(x, "t", None)):
             if t is not None:
                 t.record_stream(self.side)
+
+    def _stored(self, x):
+        """The activation of `x` as a tensor in memory: `x` itself, or the BatchNorm + ReLU it still carries applied."""
+        if x.pro is None:
+            return x
+        out = self.new(x.h, x.w, x.c)
+        L.check(self.lib.miseg_scale_shift_relu_fwd(x.ptr, out.ptr, x.pro[0].data_ptr(), x.pro[1].data_ptr(), x.pixels,
+                                                    x.c, x.pix, out.pix, self.stream()))
+        return out
+
+    def _prologue_reader(self, relu_name, xin):
+        """The layer that can apply the BatchNorm + ReLU in front of it by itself, if the activated tensor
+        `relu_name` is read by exactly one layer and that layer runs on the persistent 32-channel kernel (a 3x3
+        stride-1 convolution from 32 stored channels to at most 32, no fused addition): the two full-resolution
+        layers at the end of the U-Net decoder, whose apply passes are the largest of the step."""
+        if os.environ.get("MISEG_NO_FWD_PROLOGUE") or xin.c != 32 or xin.c0 != 0 or xin.pix != 32:
+            return None
+        cons = self.consumers.get(relu_name, [])
+        if len(cons) != 1:
+            return None
+        r = self.g.layers[cons[0]]
+        if r.cls != "Conv2D" or r.config["kernel_size"] != 3 or r.config["strides"] != 1 or \
+                r.config["padding"] != "same" or r.config.get("activation") == "relu":
+            return None
+        head = r.name == self.g.logits_layer
+        if (head and (self.head_up is not None or r.out.c > 4)) or (not head and (r.out.c > 32 or r.out.c % 8)):
+            return None
+        if not head and self._add_to_fuse(r.name) is not None:
+            return None
+        if self.fs is not None and r.name == self.fs["conv"] or self.p2 is not None and r.name == self.p2["conv"]:
+            return None
+        return r.name
 
     def _join_side(self):
         """The main stream waits for the weight gradients launched so far."""
@@ -886,6 +936,7 @@ class Trainer:
         self.fused_adds = set()
         self.cat_stats = {}
         self.cat_seeded = set()
+        self.fwd_prologues = set()      # BatchNormalizations whose apply pass the reading convolution does
         n = self.n
         self.x_in = x.contiguous()
         for name in self.order:
@@ -1041,11 +1092,16 @@ class Trainer:
                     g.layers[cons[0]].config["activation"] == "relu"
                 if not relu:
                     raise NotImplementedError("BatchNormalization without a following ReLU: %s" % name)
-                out = self.new_out(cons[0], xin.h, xin.w, c)
-                L.check(lib.miseg_scale_shift_relu_fwd(xin.ptr, out.ptr, s["scale"].data_ptr(),
-                                                       s["shift"].data_ptr(), xin.pixels, c, xin.pix,
-                                                       out.pix, st))
-                self.acts[cons[0]] = out          # the ReLU's output
+                if self._prologue_reader(cons[0], xin) is not None:
+                    # the one reader applies scale/shift + ReLU to its operand tiles: no apply pass, no second tensor
+                    self.acts[cons[0]] = Act(xin.t, c, xin.c0, pro=(s["scale"], s["shift"]))
+                    self.fwd_prologues.add(name)
+                else:
+                    out = self.new_out(cons[0], xin.h, xin.w, c)
+                    L.check(lib.miseg_scale_shift_relu_fwd(xin.ptr, out.ptr, s["scale"].data_ptr(),
+                                                           s["shift"].data_ptr(), xin.pixels, c, xin.pix,
+                                                           out.pix, st))
+                    self.acts[cons[0]] = out          # the ReLU's output
                 self.saved[name] = xin
             elif cls == "Activation":
                 continue                           # relu: fused with its BatchNormalization; softmax: head

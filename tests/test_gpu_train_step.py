@@ -61,6 +61,9 @@ def test_layerwise_forward_backward(pkg, encoder, decoder, h, w, n):
         if not err <= 6e-3:
             bad.append((name, kind, err))
     assert not bad, bad[:20]
+    # the two full-resolution BatchNorm + ReLU pairs at the end of a U-Net decoder are applied by the layers that
+    # read them (forward convolution and its weight gradient): no apply pass, no activated tensor
+    assert len(tr.fwd_prologues) == (2 if decoder == "U-Net" else 0), tr.fwd_prologues
 
 
 def test_loss_and_head_gradients_vs_oracle(pkg):
