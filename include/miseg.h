@@ -59,7 +59,8 @@ extern "C" {
 #define MISEG_TILE_SHARED_W 64  /* halo kernels: block-shared weight tiles instead of wave-private rings */
 #define MISEG_RES_ADD 0
 #define MISEG_RES_BN_RELU_MASK 1
-#define MISEG_TILE_NO_PERSIST 128 /* Cin = 32 layers and the stem: one patch per block instead of persistent blocks */
+#define MISEG_TILE_NO_PERSIST 128 /* Cin = 32 layers, the stem and the 64 -> 33..64 channel 3x3 layers: the kernel
+                                     with one patch per block instead of the persistent one */
 
 const char* miseg_last_error(void);
 int miseg_version(void);

@@ -819,6 +819,8 @@ hipError_t launch_halo_pw(const ConvParams& p, dim3 grid, hipStream_t s);
 void halo_pw_kernel_name(const ConvParams& p, char* buf, int len);
 bool conv_c32p_ok(const ConvParams& p);
 hipError_t launch_conv_c32p(const ConvParams& p, hipStream_t s);
+bool conv_c64p_ok(const ConvParams& p);
+hipError_t launch_conv_c64p(ConvParams p, hipStream_t s);
 bool conv_stem7_ok(const ConvParams& p);
 hipError_t launch_conv_stem7(ConvParams p, hipStream_t s);
 bool conv_pw_pro_ok(const ConvParams& p);
@@ -930,6 +932,8 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
                                 "", "8, 32, 4, 1, 2, 1, 1"};
   if (kc.kind == K_C32)
     snprintf(buf, len, "conv3x3_c32_kernel<8, 32>");
+  else if (kc.kind == K_HALO_PW && persist && conv_c64p_ok(pp))
+    snprintf(buf, len, "conv3x3_c64p_kernel");
   else if (kc.kind == K_HALO_PW)
     halo_pw_kernel_name(pp, buf, len);
   else if (kc.kind == K_HALO)
@@ -1098,6 +1102,14 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
   }
   if (kc.kind == K_C32 && conv_c32p_ok(p) && !(d->tile_hint & MISEG_TILE_NO_PERSIST)) {
     e = launch_conv_c32p(p, stream);
+    if (e != hipSuccess) {
+      set_error("conv launch failed: %s", hipGetErrorString(e));
+      return MISEG_E_HIP;
+    }
+    return MISEG_OK;
+  }
+  if (kc.kind == K_HALO_PW && conv_c64p_ok(p) && !(d->tile_hint & MISEG_TILE_NO_PERSIST)) {
+    e = launch_conv_c64p(p, stream);
     if (e != hipSuccess) {
       set_error("conv launch failed: %s", hipGetErrorString(e));
       return MISEG_E_HIP;

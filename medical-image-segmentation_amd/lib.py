@@ -17,6 +17,7 @@ FMT_BF16, FMT_F16 = 0, 1      # 16-bit storage format of activations and weights
 ACT_NONE, ACT_RELU, ACT_SOFTMAX, ACT_SIGMOID = 0, 1, 2, 3
 LOSS_CCE, LOSS_DICE, LOSS_FOCAL = 1, 2, 4
 RES_ADD, RES_BN_RELU_MASK = 0, 1
+TILE_NO_PERSIST = 128          # miseg_conv_desc.tile_hint flag: keep a layer off its persistent kernel
 
 
 class MisegError(RuntimeError):

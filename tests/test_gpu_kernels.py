@@ -890,3 +890,62 @@ def test_collapse_and_loss_sums(env):
     assert abs(f1 - losses.f1_score(gt[None], p[None])) < 1e-5
     assert abs(iou - losses.iou_score(gt[None], p[None])) < 1e-5
     assert abs(cce + 1 - f1 - losses.cce_dice_loss(gt[None], p[None])) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 70, 64), (1, 8, 32, 64), (1, 37, 45, 40), (2, 16, 64, 48)])
+@pytest.mark.parametrize("variant", ["plain", "res", "res_after", "res_out2", "out2_only", "linear2"])
+def test_conv_c64p(env, shape, variant):
+    """The persistent 64-channel kernel (3x3, Cin = 64, 32 < Cout <= 64: stage 1 of the ResNets built through
+    /root/reference utils/model.py:176-186) against the oracle: ragged patches and cout groups, residual before
+    and after the activation, second output (activated or linear), a launch that stores its second output only;
+    and the dispatch really takes it, while hint 12 keeps the K-split ring kernel for comparison."""
+    L, lib, dev = env
+    n, h, w, cout = shape
+    rng = np.random.default_rng(hash((shape, variant)) % 2**32)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, 64)))
+    wt = bf16_round(rng.normal(0, 0.06, (3, 3, 64, cout)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.3, cout).astype(np.float32)
+    res = bf16_round(rng.normal(0, 1, (n, h, w, cout))) if variant.startswith("res") or variant == "out2_only" else None
+    s2 = rng.uniform(0.5, 1.5, cout).astype(np.float32) if variant in ("res_out2", "out2_only", "linear2") else None
+    t2 = rng.normal(0, 0.3, cout).astype(np.float32) if s2 is not None else None
+    after = variant == "res_after"
+    act = 1 if variant in ("plain", "res_after") else 0
+    kw = dict(scale=sc, shift=sh, act=act, residual=res, res_f32=False, scale2=s2, shift2=t2, res_after=after,
+              want_out=variant != "out2_only", out2_linear=variant == "linear2")
+    got, got2 = run_conv(env, x, wt, 1, 1, **kw)
+    v = ref_conv(x, wt, 1, 1) * sc + sh
+    if res is not None and not after:
+        v = v + res
+    want = np.maximum(v, 0) if act else v
+    if after:
+        want = want + res
+    tol = 2 ** -7 if STORAGE["fmt"] == 0 else 2 ** -8
+    if got is not None:
+        np.testing.assert_allclose(got, want, rtol=tol, atol=tol * np.abs(want).max())
+    if s2 is not None:
+        want2 = v * s2 + t2
+        if variant != "linear2":
+            want2 = np.maximum(want2, 0)
+        np.testing.assert_allclose(got2, want2, rtol=tol, atol=2 * tol * np.abs(want2).max())
+    # the same launch on the K-split ring kernel
+    ring, ring2 = run_conv(env, x, wt, 1, 1, tile_hint=L.TILE_NO_PERSIST, **kw)
+    if got is not None:
+        np.testing.assert_allclose(got, ring, rtol=tol, atol=tol * np.abs(want).max())
+    if s2 is not None:
+        np.testing.assert_allclose(got2, ring2, rtol=tol, atol=2 * tol * np.abs(want).max())
+    d = new_desc(L)
+    t = torch.zeros((n, h, w, 64), dtype=h16(), device=dev)
+    d.inp = d.weight = d.out = t.data_ptr()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, w, 64, h, w, cout
+    d.KH = d.KW = 3
+    d.stride_y = d.stride_x = d.pad_y = d.pad_x = 1
+    d.in_pix_stride, d.in_row_stride, d.in_img_stride = 64, 64 * w, 64 * w * h
+    d.out_pix_stride, d.out_row_stride, d.out_img_stride = 64, 64 * w, 64 * w * h
+    d.out_dtype, d.temperature = L.DT_BF16, 1.0
+    buf = C.create_string_buffer(128)
+    L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+    assert buf.value.decode() == "conv3x3_c64p_kernel", buf.value
+    d.tile_hint = L.TILE_NO_PERSIST
+    L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+    assert buf.value.decode().startswith("conv3x3_halo_ks_kernel"), buf.value
