@@ -39,6 +39,11 @@ constexpr int C6_AHEAD = 3;                         // fragment reads run this m
 static_assert(C6_LDS <= 160 * 1024, "one block per CU");
 }  // namespace
 
+// STATS: the launch gathers the per-channel sum and sum of squares of what it stores (training forward); it then
+// has no second output, whose 32 coefficient registers the running sums take.
+// BNM (with STATS): a data gradient behind relu(bn(x)) (ConvParams::res_mask_c): `residual` is x, scale/shift
+// are the BatchNorm's forward coefficients, the sums are sum(g) and sum(g * x) of the masked result.
+template <bool STATS, bool BNM = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_c64p_kernel(const ConvParams p) {
   constexpr int HWD = C6_HWD, PITCH = C6_PITCH, NHW = C6_NHI / 8;
   __shared__ __attribute__((aligned(16))) unsigned char lds[C6_LDS];
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64p_kernel(const ConvParams p
     if (tid < 256) {
       const int which = tid >> 6, c = tid & 63;
       const float* src = which == 0 ? p.scale : which == 1 ? p.shift : which == 2 ? p.scale2 : p.shift2;
-      coef[tid] = (src && c < p.Cout) ? src[c] : ((which & 1) ? 0.f : 1.f);
+      coef[tid] = (src && c < (BNM ? p.res_mask_c : p.Cout)) ? src[c] : ((which & 1) ? 0.f : 1.f);
     }
   }
   const unsigned coef_a = lds_a + C6_COEF_OFF + (32 * g + 8 * lhalf) * 4;
@@ -87,10 +92,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64p_kernel(const ConvParams p
   dl.c2[1] = 32 * g + 16 + 8 * lhalf;
   dl.okc[0] = dl.c2[0] + 8 <= p.Cout;
   dl.okc[1] = dl.c2[1] + 8 <= p.Cout;
-  dl.okm[0] = dl.okm[1] = false;
+  dl.okm[0] = BNM && dl.c2[0] + 8 <= p.res_mask_c;
+  dl.okm[1] = BNM && dl.c2[1] + 8 <= p.res_mask_c;
   dl.relu = p.act == MISEG_ACT_RELU;
   const bool has_res = p.residual != nullptr;
-  const bool has_out2 = p.out2 != nullptr;
+  const bool has_out2 = !STATS && p.out2 != nullptr;
+  float st[STATS ? 32 : 1];
+#pragma unroll
+  for (int j = 0; j < (STATS ? 32 : 1); ++j) st[j] = 0.f;
 
   // ---- halo requests: request j of this wave fills LDS bytes [(8j + wave) * 1024, +1024) of a buffer; a lane's
   //      16 bytes belong to pixel o / 144, slot (o % 144) / 16 (slot 8 = padding).  One word per request: halo
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64p_kernel(const ConvParams p
     static_for<4>([&](auto ic) __attribute__((always_inline)) {
       constexpr int b = decltype(ic)::value >> 1, q = decltype(ic)::value & 1;
       const int oy = y0 + 2 * rp + b;
-      const bool ok = has_res && oy < p.Ho && ox < p.Wo && dl.okc[q];
+      const bool ok = has_res && oy < p.Ho && ox < p.Wo && (BNM ? dl.okm[q] : dl.okc[q]);
       const h16_t* src = ok ? reinterpret_cast<const h16_t*>(p.residual) + n * p.res_img_stride +
                                   (long long)oy * p.res_row_stride + (long long)ox * p.res_pix_stride + dl.c2[q]
                             : reinterpret_cast<const h16_t*>(zero_src);
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64p_kernel(const ConvParams p
       }
     }
     DirectOut2 d2;
-    if (has_out2) {
+    if constexpr (!STATS) if (has_out2) {
       h16x8 c[8];
       ds_read_b128_at<512>(c[0], coef_a);
       ds_read_b128_at<528>(c[1], coef_a);
@@ -249,24 +258,58 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64p_kernel(const ConvParams p
       const long long o2_off = okp && has_out2 ? n * p.out2_img_stride + (long long)oy * p.out2_row_stride +
                                                      (long long)ox * p.out2_pix_stride : 0;
       const uint4 rr[2] = {__builtin_bit_cast(uint4, rres[b][0]), __builtin_bit_cast(uint4, rres[b][1])};
-      if (p.out)
-        direct_tile<true>(p, dl, acc[b], okp, o_off, o2_off, has_res, rr, has_out2 ? &d2 : nullptr, nullptr, false);
+      if constexpr (BNM)
+        direct_tile_mask(p, dl, acc[b], okp, o_off, rr, st, true);
+      else if (p.out)
+        direct_tile<true>(p, dl, acc[b], okp, o_off, o2_off, has_res, rr, !STATS && has_out2 ? &d2 : nullptr, STATS ? st : nullptr, STATS);
       else
-        direct_tile<false>(p, dl, acc[b], okp, o_off, o2_off, has_res, rr, has_out2 ? &d2 : nullptr, nullptr, false);
+        direct_tile<false>(p, dl, acc[b], okp, o_off, o2_off, has_res, rr, !STATS && has_out2 ? &d2 : nullptr, STATS ? st : nullptr, STATS);
     });
+  }
+  if constexpr (STATS) {
+    // lanes of one half-wave hold the same couts: butterfly over the 32 pixel lanes, block sums in LDS in fp64
+    // (the order in which waves arrive must not show in the fp32 statistics derived from them), one global fp64
+    // atomic per channel and block
+#pragma unroll
+    for (int j = 0; j < 32; ++j)
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) st[j] += __shfl_xor(st[j], off, 64);
+    double* sl = reinterpret_cast<double*>(lds);
+    __syncthreads();
+    if (tid < 128) sl[tid] = 0.0;
+    __syncthreads();
+    if (lrow == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        if (dl.okc[q]) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            unsafeAtomicAdd(&sl[dl.c2[q] + j], (double)st[8 * q + j]);
+            unsafeAtomicAdd(&sl[64 + dl.c2[q] + j], (double)st[16 + 8 * q + j]);
+          }
+        }
+    }
+    __syncthreads();
+    double* dst = p.stats + (long long)(blockIdx.x % p.stats_rep) * 2 * p.stats_stride;
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      const double v = sl[tid];
+      if (c < p.Cout && v != 0.0) unsafeAtomicAdd(dst + which * p.stats_stride + c, v);
+    }
   }
 }
 
 // The layers this kernel takes over from the K-split ring kernel: 64 input channels, 33..64 output channels
-// stored 16 bits wide in 16-byte groups, optionally with a 16-bit residual at the output resolution and a second
-// output; no statistics (the training forward keeps the K-split kernel), no prologue, no mask, no head.
+// stored 16 bits wide in 16-byte groups, optionally with a 16-bit residual at the output resolution and either a
+// second output or (bf16 storage) statistics, or (bf16 storage) as a masking data gradient; no prologue, no head.
 bool conv_c64p_ok(const ConvParams& p) {
   if (p.transposed || p.dgrad_t || p.Cin != 64 || p.Cout <= 32 || p.Cout > 64 || (p.Cout & 7)) return false;
   if (p.KH != 3 || p.KW != 3 || p.stride_y != 1 || p.stride_x != 1 || p.pad_y != 1 || p.pad_x != 1) return false;
   if (p.Ho != p.H || p.Wo != p.W || !p.vec_ok || p.out_dtype != MISEG_DT_BF16 || (!p.out && !p.out2)) return false;
-  if (p.in_scale || p.res_mask_c || p.collapse_out || p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID) return false;
+  if (p.in_scale || p.collapse_out || p.act == MISEG_ACT_SOFTMAX || p.act == MISEG_ACT_SIGMOID) return false;
   if (p.residual && (p.res_dtype != MISEG_DT_BF16 || p.res_shift)) return false;
-  if (p.stats) return false;
+  if (p.stats && (MISEG_BUILD_F16 || p.out2)) return false;
+  if (p.res_mask_c && (MISEG_BUILD_F16 || !p.stats || !p.out || p.act != MISEG_ACT_NONE)) return false;
   // per-lane source offsets of the halo requests are 32-bit
   return (long long)p.H * p.in_row_stride * 2 < (1ll << 31);
 }
@@ -278,7 +321,12 @@ hipError_t launch_conv_c64p(ConvParams p, hipStream_t s) {
   p.tiles_x = (p.Wo + C6_TW - 1) / C6_TW;
   p.mtiles = p.N * p.tiles_y * p.tiles_x;
   const int blocks = p.mtiles < cus ? p.mtiles : cus;
-  hipLaunchKernelGGL(conv3x3_c64p_kernel, dim3(blocks), dim3(512), 0, s, p);
+  if (p.res_mask_c)
+    hipLaunchKernelGGL((conv3x3_c64p_kernel<!MISEG_BUILD_F16, !MISEG_BUILD_F16>), dim3(blocks), dim3(512), 0, s, p);
+  else if (p.stats)
+    hipLaunchKernelGGL(conv3x3_c64p_kernel<!MISEG_BUILD_F16>, dim3(blocks), dim3(512), 0, s, p);
+  else
+    hipLaunchKernelGGL(conv3x3_c64p_kernel<false>, dim3(blocks), dim3(512), 0, s, p);
   return hipGetLastError();
 }
 

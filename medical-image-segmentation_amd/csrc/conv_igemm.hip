@@ -933,7 +933,7 @@ void conv_kernel_name(const miseg_conv_desc* d, char* buf, int len) {
   if (kc.kind == K_C32)
     snprintf(buf, len, "conv3x3_c32_kernel<8, 32>");
   else if (kc.kind == K_HALO_PW && persist && conv_c64p_ok(pp))
-    snprintf(buf, len, "conv3x3_c64p_kernel");
+    snprintf(buf, len, "conv3x3_c64p_kernel<%s, %s>", pp.stats ? "true" : "false", pp.res_mask_c ? "true" : "false");
   else if (kc.kind == K_HALO_PW)
     halo_pw_kernel_name(pp, buf, len);
   else if (kc.kind == K_HALO)
@@ -1043,7 +1043,7 @@ int launch_conv(const miseg_conv_desc* d, hipStream_t stream) {
     // the BatchNorm-ReLU mask exists in the ring kernels, the persistent 32-channel kernel and the generic tiles
     // (bf16 storage); a layer that would run elsewhere is declined, and the caller runs the two passes instead
     const bool tiles = (kc.kind == K_REG || kc.kind == K_DMA) && cfg >= 1 && cfg <= 7 && !MISEG_BUILD_F16;
-    const bool ring = kc.kind == K_HALO_PW && !d->transposed && !MISEG_BUILD_F16;
+    const bool ring = kc.kind == K_HALO_PW && !d->transposed && !MISEG_BUILD_F16;     // (or the persistent 64-channel kernel)
     const bool c32p = kc.kind == K_C32 && conv_c32p_ok(p) && !(d->tile_hint & MISEG_TILE_NO_PERSIST) && !MISEG_BUILD_F16;
     if (!(tiles || ring || c32p) || !p.vec_ok) {
       set_error("conv: the BatchNorm-ReLU mask is not built for the kernel this layer runs on");

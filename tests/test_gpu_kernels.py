@@ -945,7 +945,7 @@ def test_conv_c64p(env, shape, variant):
     d.out_dtype, d.temperature = L.DT_BF16, 1.0
     buf = C.create_string_buffer(128)
     L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
-    assert buf.value.decode() == "conv3x3_c64p_kernel", buf.value
+    assert buf.value.decode() == "conv3x3_c64p_kernel<false, false>", buf.value
     d.tile_hint = L.TILE_NO_PERSIST
     L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
     assert buf.value.decode().startswith("conv3x3_halo_ks_kernel"), buf.value

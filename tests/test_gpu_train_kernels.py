@@ -486,7 +486,9 @@ MASK_CASES = [
     # n, h, w, cin, cout, k, stride, pad, mask_c, kernel the launcher picks
     (2, 20, 40, 64, 128, 3, 1, 1, 128, "conv3x3_halo_pw_kernel"),     # ring kernel, every channel masked
     (1, 17, 45, 128, 256, 3, 1, 1, 128, "conv3x3_halo_pw_kernel"),    # ragged patches; a skip tensor behind the mask
-    (2, 16, 32, 64, 64, 3, 1, 1, 64, "conv3x3_halo_ks_kernel"),       # K-split kernel
+    (2, 16, 32, 64, 64, 3, 1, 1, 64, "conv3x3_c64p_kernel<true, true>"),   # persistent 64-channel kernel
+    (1, 19, 45, 64, 48, 3, 1, 1, 40, "conv3x3_c64p_kernel<true, true>"),   # ragged patches, cout group and mask
+    (2, 16, 32, 128, 64, 3, 1, 1, 64, "conv3x3_halo_ks_kernel"),       # K-split kernel
     (2, 19, 70, 32, 32, 3, 1, 1, 32, "conv3x3_c32p_kernel"),          # persistent kernel: x loads issued by hand
     (1, 16, 64, 32, 32, 3, 1, 1, 16, "conv3x3_c32p_kernel"),          # the second octet of a pixel unmasked
     (2, 24, 24, 32, 64, 4, 2, 1, 64, "conv_igemm_kernel"),            # the generic tiles (a transpose-conv's gradient)
