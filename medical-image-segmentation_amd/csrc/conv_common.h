@@ -461,7 +461,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, const TileCoo
 // instruction writes 32 contiguous bytes per pixel.  Nothing here waits on anything but the
 // residual loads, which are requested four pixel rows at a time.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool direct_epilogue_ok(const ConvParams& p) {
+__host__ __device__ __forceinline__ bool direct_epilogue_ok(const ConvParams& p) {
   return p.vec_ok && p.out && p.out_dtype == MISEG_DT_BF16 && (p.Cout & 7) == 0 &&
          (!p.residual || p.res_dtype == MISEG_DT_BF16) && p.act != MISEG_ACT_SOFTMAX &&
          p.act != MISEG_ACT_SIGMOID;
