@@ -949,3 +949,19 @@ def test_conv_c64p(env, shape, variant):
     d.tile_hint = L.TILE_NO_PERSIST
     L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
     assert buf.value.decode().startswith("conv3x3_halo_ks_kernel"), buf.value
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 9, 64), (3, 8, 31, 56), (1, 70, 33, 64)])
+def test_conv_c64p_channel_slices_and_small_images(env, shape):
+    """The persistent 64-channel kernel on views: input and output as channel slices of wider tensors (what the
+    engine's concatenation buffers are), images smaller than one 8 x 32 patch, more patches than blocks."""
+    n, h, w, cout = shape
+    rng = np.random.default_rng(hash(shape) % 2**32)
+    x = bf16_round(rng.normal(0, 1, (n, h, w, 64)))
+    wt = bf16_round(rng.normal(0, 0.06, (3, 3, 64, cout)))
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.normal(0, 0.3, cout).astype(np.float32)
+    got, _ = run_conv(env, x, wt, 1, 1, scale=sc, shift=sh, act=1, in_extra_c=32, out_extra_c=64)
+    want = np.maximum(ref_conv(x, wt, 1, 1) * sc + sh, 0)
+    tol = 2 ** -7 if STORAGE["fmt"] == 0 else 2 ** -8
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol * np.abs(want).max())
