@@ -530,6 +530,10 @@ def test_conv_transpose_c64_persistent(env, shape):
         d.in_pix_stride, d.in_row_stride, d.in_img_stride = cin, cin * w, cin * w * h
         d.out_pix_stride, d.out_row_stride, d.out_img_stride = cout, cout * 2 * w, cout * 4 * w * h
         d.out_dtype, d.transposed, d.temperature = dt, 1, 1.0
+        buf = C.create_string_buffer(128)
+        L.check(lib.miseg_conv_kernel_name(C.byref(d), buf, 128))
+        # 16-bit output leaves through the direct epilogue: the 8-wave form; fp32 output keeps the 4-wave form
+        assert buf.value.decode() == ("convT_c64_kernel" if dt == L.DT_F32 else "convT_c64w8_kernel"), buf.value
         L.check(lib.miseg_conv2d_fwd(C.byref(d), None))
         torch.cuda.synchronize()
         got = out.float().cpu().numpy()
